@@ -1,0 +1,82 @@
+"""CPU checks of oracle/model_oracle.py: (a) the two independent GATConv formulations agree,
+(b) the oracle's own wiring reproduces the golden outputs captured from the reference's models.py
+(run verbatim through the dgl shim), (c) the MinMax scaler restatement matches sklearn's fp32 results."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_oracle as mo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("n", [4, 5, 9])
+def test_gat_formulations_agree(n):
+    torch.manual_seed(n)
+    G = mo.line_graph_networkx(n)
+    adj, e = mo.line_graph_closed_form(n)
+    N = G.number_of_nodes()
+    assert N == n * (n - 1) // 2 and torch.equal(e, G.ndata["e"])
+    # in-degree 2(n-2), no self loops (datasets.py:56-60)
+    assert torch.equal(adj.sum(1), torch.full((N,), 2 * (n - 2)))
+    assert len(G.src) == N * 2 * (n - 2)
+    dense_from_edges = torch.zeros((N, N), dtype=torch.bool)
+    dense_from_edges[G.dst, G.src] = True
+    assert torch.equal(dense_from_edges, adj)
+    ft = torch.randn(N, 8, 16, dtype=torch.float64)
+    el = torch.randn(N, 8, dtype=torch.float64) * 3
+    er = torch.randn(N, 8, dtype=torch.float64) * 3
+    a = mo.gat_aggregate_edge_list(ft, el, er, G.src, G.dst)
+    b = mo.gat_aggregate_dense(ft, el, er, adj)
+    assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+
+
+def build_oracle_model():
+    g = np.load(os.path.join(GOLD, "model_n5.npz"))
+    torch.manual_seed(int(g["model_seed"]))
+    model = mo.EdgeRegretModelOracle(1, 128, 1, 3, n_heads=8)
+    sd = mo.synthetic_state_dict(model, seed=int(g["sd_seed"]))
+    model.load_state_dict(sd)
+    model.eval()
+    checksum = float(sum(v.double().abs().sum() for v in sd.values() if v.dtype.is_floating_point))
+    assert checksum == float(g["sd_checksum"]), "torch RNG stream differs from the one the goldens were made with"
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"]) == 1191297
+    return model
+
+
+def test_state_dict_layout():
+    model = build_oracle_model()
+    keys = set(model.state_dict().keys())
+    assert len(model.message_passing_layers) == 8          # models.py:59-61: n_heads layers
+    for k in ("embed_layer.weight", "decision_layer.bias",
+              "message_passing_layers.7.message_passing.module.fc.weight",
+              "message_passing_layers.0.message_passing.module.attn_l",
+              "message_passing_layers.0.feed_forward.0.running_mean",
+              "message_passing_layers.0.feed_forward.1.module.0.weight",
+              "message_passing_layers.0.feed_forward.1.module.2.bias",
+              "message_passing_layers.0.feed_forward.2.running_var"):
+        assert k in keys
+
+
+@pytest.mark.parametrize("n", [5, 10, 20])
+def test_model_matches_reference_wiring(n):
+    model = build_oracle_model()
+    g = np.load(os.path.join(GOLD, f"model_n{n}.npz"))
+    G = mo.line_graph_networkx(n)
+    with torch.no_grad():
+        y = model(G, torch.from_numpy(g["x"]))
+    assert np.array_equal(y.numpy(), g["y"])      # same ops in the same order: bitwise
+
+
+def test_minmax_scaler_fp32():
+    g = np.load(os.path.join(GOLD, "misc.npz"))
+    s, m = g["scaler_scale"], g["scaler_min"]
+    # sklearn: X(float32) *= scale_(float64) ; X += min_   -> fp64 arithmetic, rounded to fp32 twice
+    fwd = (g["scaler_in"].astype(np.float64) * s).astype(np.float32)
+    fwd = (fwd.astype(np.float64) + m).astype(np.float32)
+    assert np.array_equal(fwd, g["scaler_fwd"])
+    inv = (g["scaler_inv_in"].astype(np.float64) - m).astype(np.float32)
+    inv = (inv.astype(np.float64) / s).astype(np.float32)
+    assert np.array_equal(inv, g["scaler_inv"])

@@ -1,0 +1,81 @@
+"""Pins oracle/gls_oracle.c (the CPU restatement) bit-for-bit against golden vectors captured from
+the reference's own Python (oracle/gen_golden.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gls_oracle as go
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).view(np.uint64)
+
+
+def assert_bits(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    both_nan = np.isnan(a) & np.isnan(b)
+    assert np.array_equal(bits(a)[~both_nan], bits(b)[~both_nan])
+
+
+def check_ops_case(g, prefix=""):
+    tour, D = g[prefix + "tour"], g[prefix + "D"]
+    n = len(tour) - 1
+    assert_bits(go.two_opt_delta_all(tour, D), g[prefix + "two_opt_table"])
+    assert_bits(go.relocate_delta_all(tour, D), g[prefix + "relocate_table"])
+    for fi in (0, 1):
+        for name in ("two_opt_a2a", "relocate_a2a"):
+            d, t, _ = getattr(go, name)(tour, D, bool(fi))
+            assert_bits(d, g[f"{prefix}{name}_fi{fi}_delta"])
+            assert t == g[f"{prefix}{name}_fi{fi}_tour"].tolist()
+        for name in ("two_opt_o2a", "relocate_o2a"):
+            for i in range(1, n):
+                d, t, _ = getattr(go, name)(tour, D, i, bool(fi))
+                assert_bits(d, g[f"{prefix}{name}_fi{fi}_delta"][i - 1])
+                assert t == g[f"{prefix}{name}_fi{fi}_tour"][i - 1].tolist()
+
+
+@pytest.mark.parametrize("n", [5, 8, 20, 50, 100])
+def test_operators(n):
+    check_ops_case(np.load(os.path.join(GOLD, f"ops_n{n}.npz")))
+
+
+def test_operators_ties_and_isclose():
+    g = np.load(os.path.join(GOLD, "ops_ties.npz"))
+    for c in range(int(g["n_cases"])):
+        check_ops_case(g, prefix=f"c{c}_")
+
+
+@pytest.mark.parametrize("n", [8, 20, 50, 100])
+def test_local_search(n):
+    g = np.load(os.path.join(GOLD, f"ls_n{n}.npz"))
+    for fi in (0, 1):
+        t, c, trace = go.local_search(g[f"fi{fi}_init_tour"], float(g[f"fi{fi}_init_cost"]), g["D"], bool(fi))
+        assert t == g[f"fi{fi}_tour"].tolist()
+        assert_bits(c, g[f"fi{fi}_cost"])
+        assert_bits(trace, g[f"fi{fi}_trace"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "gls_c*.npz"))), ids=os.path.basename)
+def test_guided_local_search(path):
+    g = np.load(path)
+    r = go.guided_local_search(g["D"], g["guides"], g["init_tour"], float(g["init_cost"]),
+                               perturbation_moves=int(g["perturbation_moves"]),
+                               first_improvement=bool(g["first_improvement"]),
+                               max_outer_iters=int(g["K"]))
+    assert r["outer_iters"] == int(g["K"])
+    assert_bits(r["trace"], g["trace"])
+    assert r["best_tour"] == g["best_tour"].tolist()
+    assert_bits(r["best_cost"], g["best_cost"])
+    assert np.array_equal(r["penalty"], g["penalty"])
+
+
+def test_misc():
+    g = np.load(os.path.join(GOLD, "misc.npz"))
+    assert go.nearest_neighbor(g["nn_W_weight"]) == g["nn_tour_weight"].tolist()
+    assert go.nearest_neighbor(g["nn_W_regret"]) == g["nn_tour_regret"].tolist()
+    assert_bits(go.tour_cost(g["tc_tour"], g["nn_W_weight"]), g["tc_cost"])
