@@ -1,0 +1,72 @@
+"""ctypes binding of libgnngls_hip.so (C ABI declared in include/gnngls_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libgnngls_hip.so")
+
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_i64 = ctypes.c_int64
+_f64 = ctypes.c_double
+
+# name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPES
+SIGNATURES = {
+    "gnngls_abi_version": [],
+    "gnngls_last_error": [],
+    "gnngls_gls_resident_capacity": [_int],
+    "gnngls_two_opt_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
+    "gnngls_relocate_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
+    "gnngls_best_move": [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp],
+    "gnngls_tour_cost": [_vp, _vp, _int, _int, _vp, _vp],
+    "gnngls_nearest_neighbor": [_vp, _int, _int, _int, _vp, _vp],
+    "gnngls_gls_run": [_vp, _vp, _int, _int, _int, _vp, _vp, _int, _int, _i64, _f64, _f64,
+                       _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
+}
+_RESTYPES = {"gnngls_last_error": ctypes.c_char_p}
+
+_lib = None
+
+
+class GnnglsHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (building nothing: run `python -m gnngls_amd.build` or
+    __graft_entry__.build() first).  Raises if it is absent -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(SO):
+            raise GnnglsHipError(
+                f"{SO} not found: build the HIP extension with `python -m gnngls_amd.build` "
+                "(this package has no CPU fallback)")
+        L = ctypes.CDLL(SO)
+        for name, argtypes in SIGNATURES.items():
+            f = getattr(L, name)      # AttributeError if the symbol is missing
+            f.argtypes = argtypes
+            f.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = L
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().gnngls_last_error()
+        raise GnnglsHipError(f"{what} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,683 @@
+// gls_kernels.hip -- guided local search on MI355X (gfx950), hand-written HIP.
+//
+// Replaces (reference file:line, /root/reference/gnngls/...):
+//   operators.py:6-147     two_opt / relocate move evaluation, a2a / o2a scans, move application
+//   algorithms.py:111-132  local_search
+//   algorithms.py:135-195  guided_local_search
+//   algorithms.py:9-18     nearest_neighbor            __init__.py:17-21  tour_cost
+//
+// Design (MI355X-first):
+//   * one persistent workgroup per TSP instance; the instance never leaves the CU: the fp64
+//     distance matrix and the int32 penalty matrix live in LDS as packed lower triangles
+//     (n=100: 39.6 KB + 19.8 KB), the tour is ping-ponged between two LDS arrays, and there is no
+//     host round trip per move;
+//   * an a2a scan gives one tour row (fixed i) to a wavefront and the j axis to its 64 lanes, so
+//     t[i], t[i-1] and the row constants are wave-uniform, tour reads are conflict-free and each
+//     evaluation costs two random LDS reads (the other terms are the per-position edge lengths
+//     Ef[], rebuilt in O(n) after every move);
+//   * best-improvement selection is an arg-min on the key (delta, i, j): identical to the
+//     reference's sequential strict-< scan (first minimum in enumeration order wins);
+//   * the perturbation phase (O(n) work per step, long serial chain) runs in wavefront 0 only, so
+//     it needs no workgroup barriers; the other wavefronts park on one barrier;
+//   * all floating point is fp64 with contraction OFF: the guided matrix `D + k*P`
+//     (algorithms.py:164) must round twice, np.isclose (operators.py:42) is evaluated literally.
+//
+// Bit-exactness notes are marked [exact].
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "gls_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace gnngls {
+
+constexpr int kWave = 64;
+constexpr int kNoKey = INT_MAX;
+
+__device__ __forceinline__ int make_key(int i, int j) { return (i << 16) | j; }
+
+// [exact] np.isclose(0, delta): |delta| <= atol + rtol*|delta| with rtol=1e-5, atol=1e-8.
+__device__ __forceinline__ bool close_to_zero(double delta) {
+    double ad = fabs(delta);
+    double r = 1e-5 * ad;      // one rounding
+    double rhs = 1e-8 + r;     // second rounding (contraction is off)
+    return ad <= rhs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Storage policies
+// ---------------------------------------------------------------------------------------------
+// Packed lower triangle without diagonal (symmetric D only).  The diagonal is never read by a
+// valid move evaluation for n >= 3 (all four/six endpoints are distinct nodes).
+struct TriStore {
+    const double *d;   // LDS
+    int32_t *p;        // LDS
+    static constexpr bool kSymmetric = true;
+    __device__ __forceinline__ static int idx(int a, int b) {
+        int hi = a > b ? a : b, lo = a > b ? b : a;
+        return ((hi * (hi - 1)) >> 1) + lo;
+    }
+    __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
+    __device__ __forceinline__ int pen(int a, int b) const { return p[idx(a, b)]; }
+    __device__ __forceinline__ void pen_inc(int a, int b) const { p[idx(a, b)] += 1; }
+};
+
+// Full row-major matrices in global memory (any n, asymmetric D allowed: index order follows the
+// reference exactly).  Used when the triangles do not fit in LDS and by the unit kernels.
+struct GlobalStore {
+    const double *d;
+    int32_t *p;
+    int n;
+    static constexpr bool kSymmetric = false;
+    __device__ __forceinline__ double dist(int a, int b) const { return d[(size_t)a * n + b]; }
+    __device__ __forceinline__ int pen(int a, int b) const { return p[(size_t)a * n + b]; }
+    __device__ __forceinline__ void pen_inc(int a, int b) const {
+        p[(size_t)a * n + b] += 1;
+        p[(size_t)b * n + a] += 1;
+    }
+};
+
+template <class S>
+struct PlainDist {
+    const S &s;
+    __device__ __forceinline__ double operator()(int a, int b) const { return s.dist(a, b); }
+};
+
+// [exact] edge_weight + k * edge_penalties (algorithms.py:164): product rounded, then sum rounded.
+template <class S>
+struct GuidedDist {
+    const S &s;
+    double k;
+    __device__ __forceinline__ double operator()(int a, int b) const {
+        double kp = k * (double)s.pen(a, b);
+        return s.dist(a, b) + kp;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Move evaluation, reference operand order   [exact]
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ double two_opt_cost(const int32_t *t, const F &f, int i, int j) {
+    if (i == j) return 0.0;
+    if (j < i) { int x = i; i = j; j = x; }
+    int a = t[i], b = t[i - 1], c = t[j], d = t[j - 1];
+    double delta = f(a, c) + f(b, d);      // operators.py:25-28, left to right
+    delta = delta - f(a, b);
+    delta = delta - f(c, d);
+    return delta;
+}
+
+template <class F>
+__device__ __forceinline__ double relocate_cost(const int32_t *t, const F &f, int i, int j) {
+    if (i == j) return 0.0;
+    int a = t[i - 1], b = t[i], c = t[i + 1];
+    int d, e;
+    if (i < j) { d = t[j]; e = t[j + 1]; } else { d = t[j - 1]; e = t[j]; }
+    double delta = -f(a, b);               // operators.py:97-102, left to right
+    delta = delta - f(b, c);
+    delta = delta + f(a, c);
+    delta = delta - f(d, e);
+    delta = delta + f(d, b);
+    delta = delta + f(b, e);
+    return delta;
+}
+
+// tour after a move, as a function of the old tour (operators.py:6-11, 76-80)
+__device__ __forceinline__ int two_opt_src(int p, int i, int j) {   // requires i < j
+    return (p >= i && p < j) ? (i + j - 1 - p) : p;
+}
+__device__ __forceinline__ int relocate_src(int p, int i, int j) {
+    if (i < j) {
+        if (p < i || p > j) return p;
+        return p < j ? p + 1 : i;
+    }
+    if (p < j || p > i) return p;
+    return p == j ? i : p - 1;
+}
+__device__ __forceinline__ int move_src(int op, int p, int i, int j) {
+    if (op == 0) {
+        int lo = i < j ? i : j, hi = i < j ? j : i;
+        return two_opt_src(p, lo, hi);
+    }
+    return relocate_src(p, i, j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Selection:  candidate (delta, key); "no candidate" = (0.0, kNoKey)
+//   best improvement : lexicographic min of (delta, key)       == sequential strict-< scan
+//   first improvement: min key among qualifying candidates     == first hit in enumeration order
+// ---------------------------------------------------------------------------------------------
+template <bool FI>
+__device__ __forceinline__ bool better(double d1, int k1, double d2, int k2) {
+    if (FI) return k1 < k2;
+    return d1 < d2 || (d1 == d2 && k1 < k2);
+}
+
+template <bool FI>
+__device__ __forceinline__ void consider(double delta, int key, double &bd, int &bk) {
+    if (delta < 0.0 && better<FI>(delta, key, bd, bk) && !close_to_zero(delta)) { bd = delta; bk = key; }
+}
+
+template <bool FI>
+__device__ __forceinline__ void wave_reduce_best(double &d, int &k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        double od = __shfl_xor(d, off, kWave);
+        int ok = __shfl_xor(k, off, kWave);
+        if (better<FI>(od, ok, d, k)) { d = od; k = ok; }
+    }
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS control block shared by the workgroup
+struct Ctl {
+    double red_d[2][16];
+    int red_k[2][16];
+    double cost;
+    int flag;
+    int pad;
+};
+
+template <bool FI>
+__device__ __forceinline__ void block_reduce_best(Ctl *ctl, int &phase, int wave, int nwaves, int lane,
+                                                  double &d, int &k) {
+    wave_reduce_best<FI>(d, k);
+    if (nwaves == 1) return;
+    if (lane == 0) { ctl->red_d[phase][wave] = d; ctl->red_k[phase][wave] = k; }
+    __syncthreads();
+    d = ctl->red_d[phase][0]; k = ctl->red_k[phase][0];
+    for (int w = 1; w < nwaves; ++w) {
+        double od = ctl->red_d[phase][w]; int ok = ctl->red_k[phase][w];
+        if (better<FI>(od, ok, d, k)) { d = od; k = ok; }
+    }
+    phase ^= 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2a scans on the plain matrix.  Ef[p] = dist(t[p-1], t[p]), Eb[p] = dist(t[p], t[p-1]), p=1..n.
+// ---------------------------------------------------------------------------------------------
+template <class S, bool FI>
+__device__ __forceinline__ void scan_two_opt_a2a(const S &s, const int32_t *t, const double *Eb, int n,
+                                                 int wave, int nwaves, int lane, double &bd, int &bk) {
+    // itertools.combinations(range(1,n),2), |i-j| >= 2  (operators.py:36-39)
+    for (int i = 1 + wave; i <= n - 3; i += nwaves) {
+        int a = t[i], b = t[i - 1];
+        double eab = Eb[i];                                  // D[a,b]
+        for (int j = i + 2 + lane; j <= n - 1; j += kWave) {
+            int c = t[j], d = t[j - 1];
+            double delta = s.dist(a, c) + s.dist(b, d);
+            delta = delta - eab;
+            delta = delta - Eb[j];                           // D[c,d]
+            consider<FI>(delta, make_key(i, j), bd, bk);
+        }
+    }
+}
+
+template <class S, bool FI>
+__device__ __forceinline__ void scan_relocate_a2a(const S &s, const int32_t *t, const double *Ef, int n,
+                                                  int wave, int nwaves, int lane, double &bd, int &bk) {
+    // itertools.permutations(range(1,n),2), skip i-j == 1  (operators.py:133-136)
+    for (int i = 1 + wave; i <= n - 1; i += nwaves) {
+        int a = t[i - 1], b = t[i], c = t[i + 1];
+        double base = -Ef[i];                                // -D[a,b]
+        base = base - Ef[i + 1];                             // -D[b,c]
+        base = base + s.dist(a, c);                          // +D[a,c]
+        for (int j = 1 + lane; j <= n - 1; j += kWave) {
+            if (j == i || j == i - 1) continue;
+            int d, e; double de;
+            if (i < j) { d = t[j]; e = t[j + 1]; de = Ef[j + 1]; }
+            else       { d = t[j - 1]; e = t[j]; de = Ef[j]; }
+            double delta = base - de;                        // -D[d,e]
+            delta = delta + s.dist(d, b);
+            delta = delta + s.dist(b, e);
+            consider<FI>(delta, make_key(i, j), bd, bk);
+        }
+    }
+}
+
+// o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
+template <class F, bool FI>
+__device__ __forceinline__ void scan_two_opt_o2a(const int32_t *t, const F &f, int n, int i,
+                                                 int tid, int nthr, double &bd, int &bk) {
+    for (int j = 1 + tid; j <= n - 1; j += nthr) {
+        int dj = i - j; if (dj < 0) dj = -dj;
+        if (dj < 2) continue;                                // operators.py:61-62
+        consider<FI>(two_opt_cost(t, f, i, j), j, bd, bk);
+    }
+}
+template <class F, bool FI>
+__device__ __forceinline__ void scan_relocate_o2a(const int32_t *t, const F &f, int n, int i,
+                                                  int tid, int nthr, double &bd, int &bk) {
+    for (int j = 1 + tid; j <= n - 1; j += nthr) {
+        if (j == i) continue;                                // operators.py:114-115
+        consider<FI>(relocate_cost(t, f, i, j), j, bd, bk);
+    }
+}
+
+// new tour + edge arrays in one pass; caller synchronises afterwards.
+template <class S>
+__device__ __forceinline__ void apply_move(const S &s, const int32_t *told, int32_t *tnew, double *Ef, double *Eb,
+                                           int n, int op, int i, int j, int tid, int nthr, bool want_edges) {
+    for (int p = tid; p <= n; p += nthr) {
+        int np = told[move_src(op, p, i, j)];
+        tnew[p] = np;
+        if (want_edges && p >= 1) {
+            int nq = told[move_src(op, p - 1, i, j)];
+            Ef[p] = s.dist(nq, np);
+            if (!S::kSymmetric) Eb[p] = s.dist(np, nq);
+        }
+    }
+}
+
+template <class S>
+__device__ __forceinline__ void build_edges(const S &s, const int32_t *t, double *Ef, double *Eb, int n,
+                                            int tid, int nthr) {
+    for (int p = 1 + tid; p <= n; p += nthr) {
+        int u = t[p - 1], v = t[p];
+        Ef[p] = s.dist(u, v);
+        if (!S::kSymmetric) Eb[p] = s.dist(v, u);
+    }
+}
+
+// [exact] tour_cost (__init__.py:17-21): c = 0; c += w left to right.  Ef must be current.
+__device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) {
+    double c = 0.0;
+    for (int p = 1; p <= n; ++p) c += Ef[p];
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The persistent GLS kernel
+// ---------------------------------------------------------------------------------------------
+struct Trace {
+    double *cost; float *time; int cap; int len; long long t0;
+    __device__ __forceinline__ void push(double c) {
+        if (len < cap) {
+            cost[len] = c;
+            if (time) time[len] = (float)((double)(wall_clock64() - t0) * 1e-8);
+        }
+        len++;
+    }
+};
+
+template <class S, bool FI>
+__device__ void local_search_dev(const S &s, int32_t *&t, int32_t *&t2, double *Ef, double *Eb, int n,
+                                 Ctl *ctl, int &phase, double &cur_cost, Trace &tr, long long &evals) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
+    build_edges(s, t, Ef, Eb, n, tid, nthr);
+    __syncthreads();
+    bool improved = true;
+    while (improved) {                                               // algorithms.py:116
+        improved = false;
+#pragma unroll 1
+        for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
+            double bd = 0.0; int bk = kNoKey;
+            if (op == 0) scan_two_opt_a2a<S, FI>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+            else         scan_relocate_a2a<S, FI>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+            block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
+            if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
+            if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
+                improved = true;
+                cur_cost += bd;                                      // algorithms.py:124
+                apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true);
+                int32_t *x = t; t = t2; t2 = x;
+                if (tid == 0) tr.push(cur_cost);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <class S, bool FI>
+__global__ void gls_kernel(GlsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int n = A.n;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    const size_t nn = (size_t)n * n;
+    const double *Dg = A.D + (size_t)b * nn;
+
+    // ---- LDS carve (all offsets multiples of 16) ----
+    size_t off = 0;
+    Ctl *ctl = reinterpret_cast<Ctl *>(smem + off);            off += (sizeof(Ctl) + 15) & ~size_t(15);
+    double *Ef = reinterpret_cast<double *>(smem + off);       off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15);
+    double *Eb = Ef;
+    if (!S::kSymmetric) { Eb = reinterpret_cast<double *>(smem + off); off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15); }
+    int32_t *t = reinterpret_cast<int32_t *>(smem + off);      off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
+    int32_t *t2 = reinterpret_cast<int32_t *>(smem + off);     off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
+    int32_t *bt = reinterpret_cast<int32_t *>(smem + off);     off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
+
+    S s;
+    if constexpr (S::kSymmetric) {
+        const int ntri = n * (n - 1) / 2;
+        double *dtri = reinterpret_cast<double *>(smem + off);   off += ((size_t)ntri * 8 + 15) & ~size_t(15);
+        int32_t *ptri = reinterpret_cast<int32_t *>(smem + off);
+        // row a of the lower triangle is contiguous in both the source row and the packed image
+        for (int a = 1 + wave; a < n; a += (nthr >> 6)) {
+            const double *src = Dg + (size_t)a * n;
+            double *dst = dtri + ((a * (a - 1)) >> 1);
+            for (int c = lane; c < a; c += kWave) dst[c] = src[c];
+        }
+        for (int q = tid; q < ntri; q += nthr) ptri[q] = 0;                  // algorithms.py:138
+        s.d = dtri; s.p = ptri;
+    } else {
+        s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host
+    }
+    for (int p = tid; p <= n; p += nthr) { int v = A.init_tour[(size_t)b * (n + 1) + p]; t[p] = v; bt[p] = v; }
+    __syncthreads();
+
+    const long long t_start = wall_clock64();
+    Trace tr;
+    tr.cap = A.trace_cap; tr.len = 0; tr.t0 = t_start;
+    tr.cost = A.trace_cost ? A.trace_cost + (size_t)b * A.trace_cap : nullptr;
+    tr.time = A.trace_time ? A.trace_time + (size_t)b * A.trace_cap : nullptr;
+    if (!tr.cost) tr.cap = 0;
+    const bool eager_cost = tr.cap > 0;
+
+    const double init_cost = A.init_cost[b];
+    const double k = 0.1 * init_cost / (double)n;                             // algorithms.py:137
+    double cur_cost = init_cost;
+    long long evals = 0;
+    int phase = 0;
+    int status = 0;
+
+    local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);   // algorithms.py:142
+    double best_cost = cur_cost;                                              // algorithms.py:143
+    for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
+    __syncthreads();
+
+    const long long limit_ticks = (long long)(A.time_limit_s * 1e8);
+    const long long watchdog_ticks = (long long)(A.watchdog_s * 1e8);
+    long long iter_i = 0;
+    const GuidedDist<S> gd{s, k};
+
+    for (;;) {
+        // ---- loop condition (algorithms.py:146) ----
+        if (tid == 0) {
+            long long el = wall_clock64() - t_start;
+            int go;
+            if (A.max_outer_iters >= 0) go = iter_i < A.max_outer_iters;
+            else go = el < limit_ticks;
+            if (el > watchdog_ticks) { go = 0; status = GNNGLS_STATUS_WATCHDOG_DEV; }
+            ctl->flag = go;
+        }
+        __syncthreads();
+        if (!ctl->flag) break;
+        const double *guide = A.guides + ((size_t)(iter_i % A.n_guides) * A.B + b) * nn;   // algorithms.py:147
+
+        // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
+        if (wave == 0) {
+            int moves = 0;
+            bool any_moved = false;
+            long long steps = 0;
+            while (moves < A.perturbation_moves) {
+                // arg-max utility over tour edges, first maximum wins (algorithms.py:153-159)
+                double bu = 0.0; int bp = kNoKey;
+                for (int p = lane; p < n; p += kWave) {
+                    int u = t[p], v = t[p + 1];
+                    double util = guide[(size_t)u * n + v] / (1.0 + (double)s.pen(u, v));
+                    if (bp == kNoKey || util > bu) { bu = util; bp = p; }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    double ou = __shfl_xor(bu, o, kWave); int op_ = __shfl_xor(bp, o, kWave);
+                    bool take = (op_ != kNoKey) && (bp == kNoKey || ou > bu || (ou == bu && op_ < bp));
+                    if (take) { bu = ou; bp = op_; }
+                }
+                const int eu = t[bp], ev = t[bp + 1];
+                if (lane == 0) s.pen_inc(eu, ev);                              // algorithms.py:161
+                wave_sync();
+                for (int side = 0; side < 2; ++side) {                         // algorithms.py:167
+                    const int node = side == 0 ? eu : ev;
+                    if (node == 0) continue;                                   // algorithms.py:168
+                    int i = 0;                                                 // algorithms.py:169
+                    for (int p0 = 0; p0 <= n; p0 += kWave) {
+                        int p = p0 + lane;
+                        unsigned long long m = __ballot(p <= n && t[p] == node);
+                        if (m) { i = p0 + __ffsll((long long)m) - 1; break; }
+                    }
+#pragma unroll 1
+                    for (int op = 0; op < 2; ++op) {                           // algorithms.py:171
+                        double bd = 0.0; int bk = kNoKey;
+                        if (op == 0) scan_two_opt_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
+                        else         scan_relocate_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
+                        wave_reduce_best<FI>(bd, bk);
+                        if (lane == 0) evals += (op == 0) ? (n - 3) : (n - 2);
+                        if (bk != kNoKey) {                                    // algorithms.py:175
+                            apply_move(s, t, t2, Ef, Eb, n, op, i, bk, lane, kWave, eager_cost);
+                            int32_t *x = t; t = t2; t2 = x;
+                            wave_sync();
+                            any_moved = true;
+                            moves += 1;                                        // algorithms.py:185
+                            if (eager_cost) {
+                                cur_cost = tour_cost_from_edges(Ef, n);        // algorithms.py:176
+                                if (lane == 0) tr.push(cur_cost);
+                            }
+                        }
+                    }
+                }
+                steps++;
+                if ((steps & 63) == 0) {
+                    long long el = wall_clock64() - t_start;
+                    if (el > watchdog_ticks) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
+                }
+            }
+            if (any_moved && !eager_cost) {
+                build_edges(s, t, Ef, Eb, n, lane, kWave);
+                wave_sync();
+                cur_cost = tour_cost_from_edges(Ef, n);
+            }
+            // tour buffers may have been swapped an odd number of times: publish which one is current
+            if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
+        }
+        __syncthreads();
+        {
+            int32_t *cur = reinterpret_cast<int32_t *>(smem + ctl->pad);
+            if (cur != t) { int32_t *x = t; t = t2; t2 = x; }
+            cur_cost = ctl->cost;
+        }
+
+        // ---- optimisation (algorithms.py:188) ----
+        local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);
+        if (cur_cost < best_cost) {                                            // algorithms.py:190-191
+            best_cost = cur_cost;
+            for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
+        }
+        iter_i++;
+        __syncthreads();
+    }
+
+    // ---- outputs ----
+    for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = bt[p];
+    if (tid == 0) {
+        A.best_cost[b] = best_cost;
+        if (A.outer_iters) A.outer_iters[b] = iter_i;
+        if (A.trace_len) A.trace_len[b] = tr.len;
+        if (A.evals) A.evals[b] = evals;
+        if (A.status) A.status[b] = status;
+    }
+    if (A.penalty_out) {
+        int32_t *po = A.penalty_out + (size_t)b * nn;
+        for (size_t q = tid; q < nn; q += nthr) {
+            int a = (int)(q / n), c = (int)(q % n);
+            po[q] = (a == c) ? 0 : s.pen(a, c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unit / operator kernels (global-memory store: exact reference index order, asymmetric D allowed)
+// ---------------------------------------------------------------------------------------------
+__global__ void delta_all_kernel(const int32_t *tour, const double *D, int n, int op, double *out) {
+    const int b = blockIdx.x;
+    const int32_t *t = tour + (size_t)b * (n + 1);
+    GlobalStore s{D + (size_t)b * n * n, nullptr, n};
+    PlainDist<GlobalStore> f{s};
+    double *o = out + (size_t)b * (n + 1) * (n + 1);
+    const int total = (n + 1) * (n + 1);
+    for (int q = threadIdx.x; q < total; q += blockDim.x) {
+        int i = q / (n + 1), j = q % (n + 1);
+        double v = __builtin_nan("");
+        if (i >= 1 && i <= n - 1 && j >= 1 && j <= n - 1)
+            v = op == 0 ? two_opt_cost(t, f, i, j) : relocate_cost(t, f, i, j);
+        o[q] = v;
+    }
+}
+
+template <bool FI>
+__global__ void best_move_kernel(const int32_t *tour, const double *D, int n, int op, const int32_t *pos_i,
+                                 double *delta_out, int32_t *move_out, int32_t *new_tour) {
+    __shared__ Ctl ctl;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
+    const int32_t *t = tour + (size_t)b * (n + 1);
+    GlobalStore s{D + (size_t)b * n * n, nullptr, n};
+    PlainDist<GlobalStore> f{s};
+    double bd = 0.0; int bk = kNoKey;
+    int i0 = pos_i ? pos_i[b] : 0;
+    if (pos_i) {
+        if (op == 0) scan_two_opt_o2a<PlainDist<GlobalStore>, FI>(t, f, n, i0, tid, nthr, bd, bk);
+        else         scan_relocate_o2a<PlainDist<GlobalStore>, FI>(t, f, n, i0, tid, nthr, bd, bk);
+    } else if (op == 0) {
+        for (int i = 1 + wave; i <= n - 3; i += nwaves)
+            for (int j = i + 2 + lane; j <= n - 1; j += kWave)
+                consider<FI>(two_opt_cost(t, f, i, j), make_key(i, j), bd, bk);
+    } else {
+        for (int i = 1 + wave; i <= n - 1; i += nwaves)
+            for (int j = 1 + lane; j <= n - 1; j += kWave) {
+                if (j == i || i - j == 1) continue;
+                consider<FI>(relocate_cost(t, f, i, j), make_key(i, j), bd, bk);
+            }
+    }
+    int phase = 0;
+    block_reduce_best<FI>(&ctl, phase, wave, nwaves, lane, bd, bk);
+    int mi = 0, mj = 0;
+    if (bk != kNoKey) { if (pos_i) { mi = i0; mj = bk; } else { mi = bk >> 16; mj = bk & 0xffff; } }
+    if (tid == 0) {
+        delta_out[b] = (bk != kNoKey) ? bd : 0.0;
+        move_out[2 * b] = mi; move_out[2 * b + 1] = mj;
+    }
+    if (new_tour) {
+        int32_t *o = new_tour + (size_t)b * (n + 1);
+        for (int p = tid; p <= n; p += nthr) o[p] = (bk != kNoKey) ? t[move_src(op, p, mi, mj)] : t[p];
+    }
+}
+
+__global__ void tour_cost_kernel(const int32_t *tour, const double *D, int B, int n, double *out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int32_t *t = tour + (size_t)b * (n + 1);
+    const double *d = D + (size_t)b * n * n;
+    double c = 0.0;
+    for (int p = 0; p < n; ++p) c += d[(size_t)t[p] * n + t[p + 1]];
+    out[b] = c;
+}
+
+// nearest_neighbor (algorithms.py:9-18): one wavefront per instance; ties -> lowest node id.
+__global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32_t *tour_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t *visited = smem;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double *w = W + (size_t)b * n * n;
+    int32_t *t = tour_out + (size_t)b * (n + 1);
+    for (int j = lane; j < n; j += kWave) visited[j] = (j == depot);
+    wave_sync();
+    int cur = depot;
+    if (lane == 0) { t[0] = depot; t[n] = depot; }
+    for (int len = 1; len < n; ++len) {
+        double bw = 0.0; int bj = kNoKey;
+        for (int j = lane; j < n; j += kWave) {
+            if (visited[j]) continue;
+            double x = w[(size_t)cur * n + j];
+            if (bj == kNoKey || x < bw) { bw = x; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            double ow = __shfl_xor(bw, o, kWave); int oj = __shfl_xor(bj, o, kWave);
+            bool take = (oj != kNoKey) && (bj == kNoKey || ow < bw || (ow == bw && oj < bj));
+            if (take) { bw = ow; bj = oj; }
+        }
+        if (lane == 0) { t[len] = bj; visited[bj] = 1; }
+        wave_sync();
+        cur = bj;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers
+// ---------------------------------------------------------------------------------------------
+size_t gls_lds_bytes(int n, bool tri) {
+    auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * 4);
+    if (!tri) off += r16((size_t)(n + 2) * 8);
+    if (tri) {
+        size_t ntri = (size_t)n * (n - 1) / 2;
+        off += r16(ntri * 8) + r16(ntri * 4);
+    }
+    return off;
+}
+
+int gls_block_threads(int n) {
+    if (n <= 24) return 64;
+    if (n <= 48) return 128;
+    return 256;
+}
+
+template <class S, bool FI>
+static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    auto kern = gls_kernel<S, FI>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(A.B), dim3(threads), lds, stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_gls(const GlsArgs &A, bool tri, bool first_improvement, hipStream_t stream) {
+    size_t lds = gls_lds_bytes(A.n, tri);
+    int threads = gls_block_threads(A.n);
+    if (tri) return first_improvement ? launch_gls_t<TriStore, true>(A, lds, threads, stream)
+                                      : launch_gls_t<TriStore, false>(A, lds, threads, stream);
+    return first_improvement ? launch_gls_t<GlobalStore, true>(A, lds, threads, stream)
+                             : launch_gls_t<GlobalStore, false>(A, lds, threads, stream);
+}
+
+hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(delta_all_kernel, dim3(B), dim3(256), 0, stream, tour, D, n, op, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
+                            bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,
+                            hipStream_t stream) {
+    int threads = pos_i ? 64 : gls_block_threads(n);
+    if (first_improvement)
+        hipLaunchKernelGGL(best_move_kernel<true>, dim3(B), dim3(threads), 0, stream, tour, D, n, op, pos_i, delta_out, move_out, new_tour);
+    else
+        hipLaunchKernelGGL(best_move_kernel<false>, dim3(B), dim3(threads), 0, stream, tour, D, n, op, pos_i, delta_out, move_out, new_tour);
+    return hipGetLastError();
+}
+
+hipError_t launch_tour_cost(const int32_t *tour, const double *D, int B, int n, double *out, hipStream_t stream) {
+    hipLaunchKernelGGL(tour_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, tour, D, B, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *tour_out, hipStream_t stream) {
+    size_t lds = ((size_t)n + 15) & ~size_t(15);
+    hipLaunchKernelGGL(nearest_neighbor_kernel, dim3(B), dim3(64), lds, stream, W, n, depot, tour_out);
+    return hipGetLastError();
+}
+
+}  // namespace gnngls

@@ -1,0 +1,142 @@
+"""Batched device API over the C ABI (include/gnngls_hip.h).
+
+All tensors are torch CUDA tensors used as plain device buffers; every function enqueues HIP
+kernels on the current torch stream through libgnngls_hip.so.  B = instances, n = nodes.
+The reference-signature mirrors (operators.py / algorithms.py of this package) are thin
+list-in/list-out wrappers over these.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+OP_TWO_OPT = 0
+OP_RELOCATE = 1
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.GnnglsHipError("no HIP device visible: gnngls_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def as_dev(x, dtype):
+    t = torch.as_tensor(x, dtype=dtype)
+    return t.to(_dev()).contiguous()
+
+
+def _check_shapes(tour, D):
+    B, n1 = tour.shape
+    n = n1 - 1
+    assert D.shape == (B, n, n), f"D shape {tuple(D.shape)} does not match tours [{B},{n1}]"
+    assert tour.dtype == torch.int32 and D.dtype == torch.float64
+    return B, n
+
+
+def two_opt_delta_all(tour, D):
+    """[B,n+1,n+1] fp64 table of two_opt_cost (reference operators.py:14-29)."""
+    B, n = _check_shapes(tour, D)
+    out = torch.empty((B, n + 1, n + 1), dtype=torch.float64, device=tour.device)
+    L = _lib.load()
+    _lib.check(L.gnngls_two_opt_delta_all(_lib.ptr(tour), _lib.ptr(D), B, n, _lib.ptr(out), _lib.current_stream()),
+               "two_opt_delta_all")
+    return out
+
+
+def relocate_delta_all(tour, D):
+    """[B,n+1,n+1] fp64 table of relocate_cost (reference operators.py:83-103)."""
+    B, n = _check_shapes(tour, D)
+    out = torch.empty((B, n + 1, n + 1), dtype=torch.float64, device=tour.device)
+    L = _lib.load()
+    _lib.check(L.gnngls_relocate_delta_all(_lib.ptr(tour), _lib.ptr(D), B, n, _lib.ptr(out), _lib.current_stream()),
+               "relocate_delta_all")
+    return out
+
+
+def best_move(tour, D, op, pos_i=None, first_improvement=False):
+    """One a2a (pos_i None) or o2a scan.  Returns (delta[B], move[B,2], new_tour[B,n+1])."""
+    B, n = _check_shapes(tour, D)
+    delta = torch.empty((B,), dtype=torch.float64, device=tour.device)
+    move = torch.empty((B, 2), dtype=torch.int32, device=tour.device)
+    new_tour = torch.empty_like(tour)
+    if pos_i is not None:
+        assert pos_i.dtype == torch.int32 and pos_i.shape == (B,)
+    L = _lib.load()
+    _lib.check(L.gnngls_best_move(_lib.ptr(tour), _lib.ptr(D), B, n, int(op), _lib.ptr(pos_i), int(first_improvement),
+                                  _lib.ptr(delta), _lib.ptr(move), _lib.ptr(new_tour), _lib.current_stream()),
+               "best_move")
+    return delta, move, new_tour
+
+
+def tour_cost(tour, D):
+    B, n = _check_shapes(tour, D)
+    out = torch.empty((B,), dtype=torch.float64, device=tour.device)
+    L = _lib.load()
+    _lib.check(L.gnngls_tour_cost(_lib.ptr(tour), _lib.ptr(D), B, n, _lib.ptr(out), _lib.current_stream()), "tour_cost")
+    return out
+
+
+def nearest_neighbor(W, depot=0):
+    """W [B,n,n] fp64 -> tours [B,n+1] int32 (reference algorithms.py:9-18)."""
+    B, n, n2 = W.shape
+    assert n == n2 and W.dtype == torch.float64
+    out = torch.empty((B, n + 1), dtype=torch.int32, device=W.device)
+    L = _lib.load()
+    _lib.check(L.gnngls_nearest_neighbor(_lib.ptr(W), B, n, int(depot), _lib.ptr(out), _lib.current_stream()),
+               "nearest_neighbor")
+    return out
+
+
+@dataclass
+class GlsResult:
+    best_tour: torch.Tensor      # [B,n+1] int32
+    best_cost: torch.Tensor      # [B] fp64
+    outer_iters: torch.Tensor    # [B] int64
+    trace_cost: torch.Tensor     # [B,T] fp64 or None
+    trace_time: torch.Tensor     # [B,T] fp32 or None
+    trace_len: torch.Tensor      # [B] int32
+    penalty: torch.Tensor        # [B,n,n] int32 or None
+    evals: torch.Tensor          # [B] int64
+    status: torch.Tensor         # [B] int32
+
+
+def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improvement=False,
+            max_outer_iters=-1, time_limit_s=0.0, watchdog_s=None, trace_cap=0, want_trace_time=False,
+            want_penalty=False):
+    """guided_local_search (reference algorithms.py:135-195) for a batch of instances.
+
+    D [B,n,n] fp64 symmetric, guides [G,B,n,n] fp64 (or None when max_outer_iters == 0 ->
+    local_search only), init_tour [B,n+1] int32, init_cost [B] fp64."""
+    B, n = _check_shapes(init_tour, D)
+    dev = D.device
+    G = 0
+    if guides is not None:
+        assert guides.dtype == torch.float64 and guides.dim() == 4 and guides.shape[1:] == (B, n, n)
+        G = guides.shape[0]
+    assert init_cost.dtype == torch.float64 and init_cost.shape == (B,)
+    if watchdog_s is None:
+        watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 120.0
+    best_tour = torch.empty_like(init_tour)
+    best_cost = torch.empty((B,), dtype=torch.float64, device=dev)
+    outer = torch.zeros((B,), dtype=torch.int64, device=dev)
+    trace_cost = torch.zeros((B, trace_cap), dtype=torch.float64, device=dev) if trace_cap > 0 else None
+    trace_time = torch.zeros((B, trace_cap), dtype=torch.float32, device=dev) if (trace_cap > 0 and want_trace_time) else None
+    trace_len = torch.zeros((B,), dtype=torch.int32, device=dev)
+    penalty = torch.zeros((B, n, n), dtype=torch.int32, device=dev) if want_penalty else None
+    evals = torch.zeros((B,), dtype=torch.int64, device=dev)
+    status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    L = _lib.load()
+    _lib.check(L.gnngls_gls_run(
+        _lib.ptr(D), _lib.ptr(guides), G, B, n, _lib.ptr(init_tour), _lib.ptr(init_cost),
+        int(perturbation_moves), int(first_improvement), ctypes.c_int64(int(max_outer_iters)),
+        float(time_limit_s), float(watchdog_s),
+        _lib.ptr(best_tour), _lib.ptr(best_cost), _lib.ptr(outer),
+        _lib.ptr(trace_cost), _lib.ptr(trace_time), int(trace_cap), _lib.ptr(trace_len),
+        _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status), _lib.current_stream()), "gls_run")
+    return GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
+
+
+def gls_resident_capacity(n):
+    return _lib.load().gnngls_gls_resident_capacity(int(n))

@@ -1,0 +1,109 @@
+/*
+ * include/gnngls_hip.h -- C ABI of libgnngls_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the hot path of proroklab/gnngls (edge-regret GNN forward +
+ * guided local search).  The reference has no FFI layer of its own: its boundary is the Python
+ * call surface.  Each entry point below cites the reference function it
+ * replaces (file:line into the reference tree); the gnngls_amd Python package binds them with ctypes and
+ * re-exposes the reference's Python signatures (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch CUDA tensor .data_ptr()) unless the
+ *     name ends in _host; buffers are caller-owned, contiguous, row-major; nothing is retained;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *   - B = number of independent TSP instances in the batch, n = nodes per instance;
+ *     a tour is int32[n+1] with the depot (node 0) at both ends (algorithms.py:10,17);
+ *     D is an n*n fp64 matrix indexed by node label (nx.attr_matrix, algorithms.py:140);
+ *     N = n(n-1)/2 line-graph nodes (= TSP edges i<j in itertools.combinations order);
+ *   - return value: 0 on success, negative on error; gnngls_last_error() gives the message.
+ *     There is NO CPU fallback anywhere in this library.
+ */
+#ifndef GNNGLS_HIP_H
+#define GNNGLS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNGLS_OK 0
+#define GNNGLS_ERR_ARG (-1)
+#define GNNGLS_ERR_HIP (-2)
+#define GNNGLS_ERR_UNSUPPORTED (-3)
+
+/* operator codes for gnngls_best_move */
+#define GNNGLS_OP_TWO_OPT 0
+#define GNNGLS_OP_RELOCATE 1
+
+/* per-instance status words written by gnngls_gls_run */
+#define GNNGLS_STATUS_OK 0
+#define GNNGLS_STATUS_WATCHDOG 1      /* watchdog fired (search aborted, best-so-far returned) */
+
+int gnngls_abi_version(void);
+const char *gnngls_last_error(void);
+
+/* Number of instances of size n that can be co-resident on the device for gnngls_gls_run
+ * (one workgroup per instance, LDS-resident distance/penalty triangles); 0 if n needs the
+ * global-memory fallback.  Host-side query, no device work. */
+int gnngls_gls_resident_capacity(int n);
+
+/* ---- K3u: move-evaluation tables (parity/unit kernels) ---------------------------------------
+ * out[b][i][j] (shape [B, n+1, n+1]) = two_opt_cost(tour_b, D_b, i, j)   operators.py:14-29
+ *                                    = relocate_cost(tour_b, D_b, i, j)  operators.py:83-103
+ * for 1 <= i,j <= n-1; NaN elsewhere.  D may be asymmetric (index order follows the reference). */
+int gnngls_two_opt_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream);
+int gnngls_relocate_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream);
+
+/* ---- one scan of a move operator --------------------------------------------------------------
+ * op = GNNGLS_OP_TWO_OPT : two_opt_a2a (operators.py:32-50) / two_opt_o2a (operators.py:53-73)
+ * op = GNNGLS_OP_RELOCATE: relocate_a2a (operators.py:129-147) / relocate_o2a (operators.py:106-126)
+ * pos_i == NULL -> all-to-all scan; else one-to-all from position pos_i[b] (must be in 1..n-1,
+ * the reference asserts this at operators.py:54,107; violating it returns GNNGLS_ERR_ARG only if
+ * checked on the host side by the caller -- the kernel clamps nothing).
+ * Acceptance rule operators.py:42,65,118,139: delta < best and not np.isclose(0, delta).
+ * Outputs: delta_out[b] (0.0 if no move), move_out[b] = {i, j} ({0,0} if none),
+ *          new_tour[b] = tour after the move (copy of the input if none). */
+int gnngls_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
+                     int first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,
+                     void *stream);
+
+/* ---- tour_cost (gnngls/__init__.py:17-21): sequential left-to-right fp64 sum ------------------ */
+int gnngls_tour_cost(const int32_t *tour, const double *D, int B, int n, double *cost_out, void *stream);
+
+/* ---- nearest_neighbor (algorithms.py:9-18) on a dense weight matrix W[B,n,n]; ties -> lowest id */
+int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *tour_out, void *stream);
+
+/* ---- K3: guided_local_search (algorithms.py:135-195), local_search (algorithms.py:111-132) -----
+ * One persistent workgroup per instance.
+ *   D            [B,n,n] fp64, symmetric (it comes from nx.attr_matrix of an undirected graph)
+ *   guides       [n_guides,B,n,n] fp64 utility numerators G.edges[e][guide] (algorithms.py:155),
+ *                cycled per outer iteration (algorithms.py:147); may be NULL iff max_outer_iters == 0
+ *   init_tour    [B,n+1], init_cost [B]
+ *   max_outer_iters >= 0 : run exactly this many outer iterations (deterministic / parity mode);
+ *                          0 = local_search only (algorithms.py:142)
+ *   max_outer_iters <  0 : run until time_limit_s seconds of device wall clock have elapsed since
+ *                          the workgroup started (reference mode, `while time.time() < t_lim`)
+ *   watchdog_s   hard abort (status GNNGLS_STATUS_WATCHDOG) if a workgroup runs longer than this
+ *   outputs      best_tour [B,n+1], best_cost [B], outer_iters [B] (int64),
+ *                trace_cost [B,trace_cap] cost after every accepted move (algorithms.py:127-130,
+ *                180-183), trace_time [B,trace_cap] seconds since workgroup start (optional),
+ *                trace_len [B] = number of accepted moves (may exceed trace_cap),
+ *                penalty_out [B,n,n] int32 final penalties (optional),
+ *                evals_out [B] int64 number of delta evaluations (optional), status [B] (optional)
+ * If trace_cap == 0 the per-move tour_cost recomputation (algorithms.py:176) is deferred to the
+ * end of each perturbation phase -- the values that drive decisions are unchanged. */
+int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, int n,
+                   const int32_t *init_tour, const double *init_cost,
+                   int perturbation_moves, int first_improvement,
+                   int64_t max_outer_iters, double time_limit_s, double watchdog_s,
+                   int32_t *best_tour, double *best_cost, int64_t *outer_iters,
+                   double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
+                   int32_t *penalty_out, int64_t *evals_out, int32_t *status, void *stream);
+
+/* ---- K1/K2: edge-regret GNN forward (models.py:44-70) -- declared in gnngls_model.h ------------ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNGLS_HIP_H */

@@ -1,0 +1,196 @@
+"""GPU parity tests of the guided-local-search HIP path (through the C ABI) against
+(a) golden vectors captured from the reference and (b) the CPU oracle on seeded random inputs.
+Bit-exact: fp64 costs/deltas compared by bit pattern, tours and moves by value."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).view(np.uint64)
+
+
+def assert_bits(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    assert np.array_equal(bits(a)[~both_nan], bits(b)[~both_nan])
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gnngls_amd import ops as o
+    return o
+
+
+def dev(x, dtype):
+    return torch.as_tensor(np.ascontiguousarray(x)).to(dtype).cuda().contiguous()
+
+
+def random_instances(rng, B, n):
+    pos = rng.random((B, n, 2))
+    d = pos[:, :, None, :] - pos[:, None, :, :]
+    D = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])
+    D = np.triu(D, 1)
+    D = D + D.transpose(0, 2, 1)
+    tours = np.zeros((B, n + 1), dtype=np.int32)
+    for b in range(B):
+        tours[b, 1:n] = 1 + rng.permutation(n - 1)
+    return D, tours
+
+
+def check_ops_case(ops, g, prefix=""):
+    tour, D = g[prefix + "tour"], g[prefix + "D"]
+    n = len(tour) - 1
+    t, d = dev(tour[None], torch.int32), dev(D[None], torch.float64)
+    assert_bits(ops.two_opt_delta_all(t, d)[0].cpu().numpy(), g[prefix + "two_opt_table"])
+    assert_bits(ops.relocate_delta_all(t, d)[0].cpu().numpy(), g[prefix + "relocate_table"])
+    for fi in (0, 1):
+        for op, name in ((0, "two_opt"), (1, "relocate")):
+            delta, move, nt = ops.best_move(t, d, op, None, bool(fi))
+            assert_bits(delta.cpu().numpy()[0], g[f"{prefix}{name}_a2a_fi{fi}_delta"])
+            assert nt[0].cpu().tolist() == g[f"{prefix}{name}_a2a_fi{fi}_tour"].tolist()
+            # all o2a positions as one batch
+            B = n - 1
+            tb = t.expand(B, -1).contiguous()
+            db = d.expand(B, -1, -1).contiguous()
+            pos = torch.arange(1, n, dtype=torch.int32, device="cuda")
+            delta, move, nt = ops.best_move(tb, db, op, pos, bool(fi))
+            assert_bits(delta.cpu().numpy(), g[f"{prefix}{name}_o2a_fi{fi}_delta"])
+            assert np.array_equal(nt.cpu().numpy(), g[f"{prefix}{name}_o2a_fi{fi}_tour"])
+
+
+@pytest.mark.parametrize("n", [5, 8, 20, 50, 100])
+def test_operators_golden(ops, n):
+    check_ops_case(ops, np.load(os.path.join(GOLD, f"ops_n{n}.npz")))
+
+
+def test_operators_ties_and_isclose_golden(ops):
+    g = np.load(os.path.join(GOLD, "ops_ties.npz"))
+    for c in range(int(g["n_cases"])):
+        check_ops_case(ops, g, prefix=f"c{c}_")
+
+
+@pytest.mark.parametrize("n", [8, 20, 50, 100])
+def test_local_search_golden(ops, n):
+    g = np.load(os.path.join(GOLD, f"ls_n{n}.npz"))
+    d = dev(g["D"][None], torch.float64)
+    for fi in (0, 1):
+        r = ops.gls_run(d, None, dev(g[f"fi{fi}_init_tour"][None], torch.int32),
+                        dev(np.array([g[f"fi{fi}_init_cost"]]), torch.float64),
+                        first_improvement=bool(fi), max_outer_iters=0, trace_cap=4096)
+        L = int(r.trace_len[0])
+        assert r.best_tour[0].cpu().tolist() == g[f"fi{fi}_tour"].tolist()
+        assert_bits(r.best_cost.cpu().numpy()[0], g[f"fi{fi}_cost"])
+        assert_bits(r.trace_cost[0, :L].cpu().numpy(), g[f"fi{fi}_trace"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "gls_c*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("trace", [True, False])
+def test_guided_local_search_golden(ops, path, trace):
+    g = np.load(path)
+    d = dev(g["D"][None], torch.float64)
+    guides = dev(g["guides"][:, None], torch.float64)
+    r = ops.gls_run(d, guides, dev(g["init_tour"][None], torch.int32), dev(np.array([g["init_cost"]]), torch.float64),
+                    perturbation_moves=int(g["perturbation_moves"]), first_improvement=bool(g["first_improvement"]),
+                    max_outer_iters=int(g["K"]), trace_cap=8192 if trace else 0, want_penalty=True)
+    assert int(r.status[0]) == 0
+    assert int(r.outer_iters[0]) == int(g["K"])
+    assert int(r.trace_len[0]) == len(g["trace"])
+    if trace:
+        assert_bits(r.trace_cost[0, :len(g["trace"])].cpu().numpy(), g["trace"])
+    assert r.best_tour[0].cpu().tolist() == g["best_tour"].tolist()
+    assert_bits(r.best_cost.cpu().numpy()[0], g["best_cost"])
+    assert np.array_equal(r.penalty[0].cpu().numpy(), g["penalty"])
+
+
+def test_misc_golden(ops):
+    g = np.load(os.path.join(GOLD, "misc.npz"))
+    for key in ("weight", "regret"):
+        t = ops.nearest_neighbor(dev(g[f"nn_W_{key}"][None], torch.float64))
+        assert t[0].cpu().tolist() == g[f"nn_tour_{key}"].tolist()
+    c = ops.tour_cost(dev(g["tc_tour"][None], torch.int32), dev(g["nn_W_weight"][None], torch.float64))
+    assert_bits(c.cpu().numpy()[0], g["tc_cost"])
+
+
+@pytest.mark.parametrize("n,B,K", [(7, 16, 6), (20, 32, 10), (33, 16, 6), (64, 8, 4), (65, 8, 4), (100, 16, 3), (130, 4, 2)])
+def test_gls_batch_vs_oracle(ops, n, B, K):
+    """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup."""
+    from oracle import gls_oracle as go
+    rng = np.random.default_rng(1000 + n)
+    D, _ = random_instances(rng, B, n)
+    guide = np.maximum(rng.normal(0.05, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)
+    guide = np.triu(guide, 1)
+    guide = guide + guide.transpose(0, 2, 1)
+    guides = np.stack([guide, D])
+    d, gd = dev(D, torch.float64), dev(guides, torch.float64)
+    init = ops.nearest_neighbor(gd[0])
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=1 << 14, want_penalty=True)
+    init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
+    for b in range(B):
+        assert init_h[b].tolist() == go.nearest_neighbor(guide[b])
+        assert_bits(cost_h[b], go.tour_cost(init_h[b], D[b]))
+        o = go.guided_local_search(D[b], guides[:, b], init_h[b], cost_h[b], perturbation_moves=20, max_outer_iters=K)
+        L = o["trace_len"]
+        assert int(r.trace_len[b]) == L
+        assert_bits(r.trace_cost[b, :L].cpu().numpy(), o["trace"])
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert_bits(r.best_cost[b].item(), o["best_cost"])
+        assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"])
+        assert int(r.evals[b]) == o["evals"]
+
+
+def test_gls_global_store_fallback(ops):
+    """n too large for the LDS triangles -> global-memory store path; same results as the oracle."""
+    from oracle import gls_oracle as go
+    n, B, K = 210, 2, 1
+    assert ops.gls_resident_capacity(n) == 0
+    rng = np.random.default_rng(7)
+    D, tours = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=10, max_outer_iters=K, trace_cap=1 << 14)
+    for b in range(B):
+        o = go.guided_local_search(D[b], D[b][None], init[b].cpu().numpy(), cost[b].item(), perturbation_moves=10,
+                                   max_outer_iters=K)
+        assert int(r.trace_len[b]) == o["trace_len"]
+        assert_bits(r.trace_cost[b, :o["trace_len"]].cpu().numpy(), o["trace"])
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+
+
+def test_gls_time_mode_and_properties(ops):
+    """Wall-clock mode at TSP100: valid tours, cost == tour_cost(best_tour), never worse than the
+    local-search-only result, and the deterministic K-iteration trace is a prefix of a longer run."""
+    n, B = 100, 64
+    rng = np.random.default_rng(5)
+    D, _ = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    g = d[None].contiguous()
+    ls = ops.gls_run(d, None, init, cost, max_outer_iters=0)
+    r = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=0.5)
+    torch.cuda.synchronize()
+    assert (r.status == 0).all()
+    assert (r.outer_iters > 0).all()
+    assert (r.best_cost <= ls.best_cost).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
+    assert all(sorted(row[:-1].tolist()) == list(range(n)) for row in bt)
+    rc = ops.tour_cost(r.best_tour, d)
+    assert torch.allclose(rc, r.best_cost, rtol=1e-12, atol=1e-12)
+    a = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=3, trace_cap=4096)
+    b2 = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=6, trace_cap=4096)
+    for b in range(B):
+        La = int(a.trace_len[b])
+        assert int(b2.trace_len[b]) >= La
+        assert torch.equal(a.trace_cost[b, :La], b2.trace_cost[b, :La])
