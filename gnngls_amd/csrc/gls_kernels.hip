@@ -462,6 +462,8 @@ __global__ void gls_kernel(GlsArgs A) {
                             if (eager_cost) {
                                 cur_cost = tour_cost_from_edges(Ef, n);        // algorithms.py:176
                                 if (lane == 0) tr.push(cur_cost);
+                            } else if (lane == 0) {
+                                tr.len++;                                      // move counted, cost deferred
                             }
                         }
                     }
