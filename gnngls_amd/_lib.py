@@ -25,8 +25,14 @@ SIGNATURES = {
     "gnngls_nearest_neighbor": [_vp, _int, _int, _int, _vp, _vp],
     "gnngls_gls_run": [_vp, _vp, _int, _int, _int, _vp, _vp, _int, _int, _i64, _f64, _f64,
                        _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
+    "gnngls_model_packed_floats": [_int, _int],
+    "gnngls_regret_forward_workspace_bytes": [_int, _int],
+    "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
+    "gnngls_pack_features": [_vp, _int, _int, _f64, _f64, _vp, _vp],
+    "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
 }
-_RESTYPES = {"gnngls_last_error": ctypes.c_char_p}
+_RESTYPES = {"gnngls_last_error": ctypes.c_char_p, "gnngls_model_packed_floats": ctypes.c_int64,
+             "gnngls_regret_forward_workspace_bytes": ctypes.c_int64}
 
 _lib = None
 

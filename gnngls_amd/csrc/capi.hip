@@ -8,6 +8,7 @@
 
 #include "../../include/gnngls_hip.h"
 #include "gls_kernels.h"
+#include "model_kernels.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -129,6 +130,92 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     hipError_t e = gnngls::launch_gls(A, tri, first_improvement != 0, st);
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// GNN forward
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr long kLayerFloats = 128L * 128 + 128 + 128 + 128 + 128 + 512L * 128 + 512 + 128L * 512 + 128 + 128 + 128;
+constexpr long kBytesPerNode = (128 + 128 + 256 + 32 + 128 + 512) * 4L;   // h, ft, part, part_ms, h1, hid
+}  // namespace
+
+extern "C" {
+
+int64_t gnngls_model_packed_floats(int in_dim, int n_layers) {
+    return 128L * in_dim + 128 + (long)n_layers * kLayerFloats + 128 + 4;
+}
+
+int64_t gnngls_regret_forward_workspace_bytes(int B, int n) {
+    long N = (long)n * (n - 1) / 2;
+    return (int64_t)B * N * kBytesPerNode + 256;
+}
+
+int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
+                          float *y_out, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!feat || !weights || !y_out || !workspace || B < 0 || n < 3 || in_dim < 1 || n_layers < 0)
+        return fail(GNNGLS_ERR_ARG, "regret_forward: bad argument");
+    if ((in_dim * 128) % 4 != 0) return fail(GNNGLS_ERR_UNSUPPORTED, "regret_forward: in_dim*128 must be a multiple of 4");
+    if (gnngls::gat_rows_lds_bytes(n) > kLdsPerCU)
+        return fail(GNNGLS_ERR_UNSUPPORTED, "regret_forward: n=%d needs %zu B of LDS per row tile (> 160 KiB)", n,
+                    gnngls::gat_rows_lds_bytes(n));
+    if (B == 0) return GNNGLS_OK;
+    const long N = (long)n * (n - 1) / 2;
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    int64_t avail = workspace_bytes - (int64_t)(base - (uintptr_t)workspace);
+    long Bc = avail / (N * kBytesPerNode);
+    if (Bc < 1) return fail(GNNGLS_ERR_ARG, "regret_forward: workspace too small (%lld B, need >= %lld B)",
+                            (long long)workspace_bytes, (long long)gnngls_regret_forward_workspace_bytes(1, n));
+    if (Bc > B) Bc = B;
+    hipStream_t st = (hipStream_t)stream;
+    const long Mc = Bc * N;
+    float *h = (float *)base;
+    float *ft = h + Mc * 128;
+    float *part = ft + Mc * 128;
+    float *part_ms = part + 2 * Mc * 128;
+    float *h1 = part_ms + 2 * Mc * 16;
+    float *hid = h1 + Mc * 128;
+    const float *emb_w = weights, *emb_b = weights + 128L * in_dim;
+    const float *layers = emb_b + 128;
+    const float *dec_w = layers + (long)n_layers * kLayerFloats, *dec_b = dec_w + 128;
+    hipError_t e = hipSuccess;
+#define GNNGLS_TRY(x) do { e = (x); if (e != hipSuccess) return hip_fail(e, #x); } while (0)
+    for (long b0 = 0; b0 < B; b0 += Bc) {
+        const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
+        const long M = (long)bc * N;
+        GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st));     // models.py:66
+        for (int l = 0; l < n_layers; ++l) {                                                          // models.py:67-68
+            const float *w = layers + (long)l * kLayerFloats;
+            const float *fc_w = w, *attn_l = fc_w + 128L * 128, *attn_r = attn_l + 128;
+            const float *bn1_s = attn_r + 128, *bn1_b = bn1_s + 128;
+            const float *w1 = bn1_b + 128, *b1 = w1 + 512L * 128, *w2 = b1 + 512, *b2 = w2 + 128L * 512;
+            const float *bn2_s = b2 + 128, *bn2_b = bn2_s + 128;
+            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st));
+            GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st));
+            GNNGLS_TRY(gnngls::launch_gat_combine(part, part_ms, h, bn1_s, bn1_b, h1, M, st));
+            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, h1, w1, hid, M, 512, 128, b1, nullptr, nullptr, nullptr, st));
+            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_SKIP_BN, hid, w2, h, M, 128, 512, b2, h1, bn2_s, bn2_b, st));
+        }
+        GNNGLS_TRY(gnngls::launch_decision(h, dec_w, dec_b, y_out + b0 * N, M, st));                  // models.py:69
+    }
+#undef GNNGLS_TRY
+    return GNNGLS_OK;
+}
+
+int gnngls_pack_features(const double *D, int B, int n, double scale, double min_, float *feat, void *stream) {
+    if (!D || !feat || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "pack_features: bad argument");
+    if (B == 0) return GNNGLS_OK;
+    hipError_t e = gnngls::launch_pack_features(D, B, n, scale, min_, feat, (hipStream_t)stream);
+    return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "pack_features");
+}
+
+int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream) {
+    if (!y || !out || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "unpack_regret: bad argument");
+    if (B == 0) return GNNGLS_OK;
+    hipError_t e = gnngls::launch_unpack_regret(y, B, n, scale, min_, out, (hipStream_t)stream);
+    return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "unpack_regret");
 }
 
 }  // extern "C"

@@ -1,0 +1,22 @@
+// model_kernels.h -- internal interface between the GNN forward kernels (model_kernels.hip) and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gnngls {
+
+enum { GEMM_EPI_STORE = 0, GEMM_EPI_BIAS_RELU = 1, GEMM_EPI_BIAS_SKIP_BN = 2 };
+
+size_t gat_rows_lds_bytes(int n);
+hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st);
+hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, double minv, double *out, hipStream_t st);
+hipError_t launch_embed(const float *x, const float *W, const float *b, float *h, long M, int in_dim, hipStream_t st);
+hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
+                       const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st);
+hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
+                           float *part_ms, hipStream_t st);
+hipError_t launch_gat_combine(const float *part, const float *part_ms, const float *h, const float *bn_scale,
+                              const float *bn_shift, float *out, long M, hipStream_t st);
+hipError_t launch_decision(const float *h, const float *w, const float *b, float *y, long M, hipStream_t st);
+
+}  // namespace gnngls

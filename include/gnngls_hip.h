@@ -101,7 +101,40 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
                    int32_t *penalty_out, int64_t *evals_out, int32_t *status, void *stream);
 
-/* ---- K1/K2: edge-regret GNN forward (models.py:44-70) -- declared in gnngls_model.h ------------ */
+/* ---- K1/K2: edge-regret GNN forward ------------------------------------------------------------
+ * EdgePropertyPredictionModel.forward (models.py:44-70) on the line graph of K_n (datasets.py:56-60),
+ * specialised to the reference architecture: embed_dim 128, 8 heads x 16 (GATConv(128,16,8),
+ * models.py:23), MLP hidden 512 (models.py:60), out_dim 1, eval-mode BatchNorm.  Layer count is a
+ * run-time argument (the reference builds n_heads layers, models.py:59-61).
+ *
+ * Packed fp32 weight image (all blocks 16-byte aligned), in this order:
+ *   embed_w[128*in_dim] embed_b[128]
+ *   per layer: fc_w[128*128] attn_l[128] attn_r[128] bn1_scale[128] bn1_shift[128]
+ *              w1[512*128] b1[512] w2[128*512] b2[128] bn2_scale[128] bn2_shift[128]
+ *   dec_w[128] dec_b[1] pad[3]
+ * where bn_scale = gamma / sqrt(running_var + eps), bn_shift = beta - running_mean * bn_scale
+ * (eval-mode BatchNorm1d, models.py:28,35).  gnngls_amd.models packs a reference state_dict.
+ *
+ *   feat [B,N,in_dim] fp32 scaled edge features in line-graph node order (node = rank of (i<j) in
+ *        itertools.combinations order); y_out [B,N] fp32.
+ *   workspace: device scratch of at least gnngls_regret_forward_workspace_bytes(1, n) bytes; if it
+ *        is smaller than the full-batch size the batch is processed in instance chunks. */
+#define GNNGLS_MODEL_EMBED_DIM 128
+#define GNNGLS_MODEL_HEADS 8
+#define GNNGLS_MODEL_HIDDEN 512
+int64_t gnngls_model_packed_floats(int in_dim, int n_layers);
+int64_t gnngls_regret_forward_workspace_bytes(int B, int n);
+int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
+                          float *y_out, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* get_scaled_features (datasets.py:73-95) for features=[weight] (datasets.py:14-20):
+ * feat[b, rank(i<j)] = MinMaxScaler.transform(float32(D[b,i,j])) with sklearn's fp32 arithmetic
+ * (x*scale_ rounded to fp32, + min_ rounded to fp32). */
+int gnngls_pack_features(const double *D, int B, int n, double scale, double min_, float *feat, void *stream);
+
+/* test.py:79-83: regret_pred = max(MinMaxScaler.inverse_transform(y_pred), 0) as a symmetric fp64
+ * [B,n,n] matrix (zero diagonal) -- the 'regret_pred' guide of guided_local_search. */
+int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream);
 
 #ifdef __cplusplus
 }
