@@ -30,7 +30,26 @@ SIGNATURES = {
     "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
     "gnngls_pack_features": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
+    "gnngls_profile_enable": [_int],
+    "gnngls_profile_collect": [_vp, _vp],
 }
+
+PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine", "gemm_ffn1", "gemm_ffn2",
+              "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls"]
+
+
+def profile_enable(on=True):
+    check(load().gnngls_profile_enable(int(on)), "profile_enable")
+
+
+def profile_collect():
+    """-> {kind: (milliseconds, launches)} since profile_enable(True)."""
+    n = len(PROF_KINDS)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    check(load().gnngls_profile_collect(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p)),
+          "profile_collect")
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 _RESTYPES = {"gnngls_last_error": ctypes.c_char_p, "gnngls_model_packed_floats": ctypes.c_int64,
              "gnngls_regret_forward_workspace_bytes": ctypes.c_int64}
 

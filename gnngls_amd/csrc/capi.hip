@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/gnngls_hip.h"
 #include "gls_kernels.h"
 #include "model_kernels.h"
@@ -24,6 +26,24 @@ int fail(int code, const char *fmt, ...) {
 int hip_fail(hipError_t e, const char *what) {
     return fail(GNNGLS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
+
+// ---- optional per-kernel-class timing with HIP events on the caller's stream -------------------
+struct ProfSpan { int kind; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfSpan> g_spans;
+
+struct ProfScope {
+    int kind; hipStream_t st; hipEvent_t a = nullptr;
+    ProfScope(int k, hipStream_t s) : kind(k), st(s) {
+        if (g_prof_on && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, st); else a = nullptr;
+    }
+    ~ProfScope() {
+        if (!a) return;
+        hipEvent_t b;
+        if (hipEventCreate(&b) == hipSuccess) { (void)hipEventRecord(b, st); g_spans.push_back({kind, a, b}); }
+        else (void)hipEventDestroy(a);
+    }
+};
 
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr int kMaxWavesPerCU = 32;
@@ -81,6 +101,7 @@ int gnngls_best_move(const int32_t *tour, const double *D, int B, int n, int op,
 int gnngls_tour_cost(const int32_t *tour, const double *D, int B, int n, double *cost_out, void *stream) {
     if (!tour || !D || !cost_out || B < 0 || n < 1) return fail(GNNGLS_ERR_ARG, "tour_cost: bad argument");
     if (B == 0) return GNNGLS_OK;
+    ProfScope ps(GNNGLS_PROF_TOUR_COST, (hipStream_t)stream);
     hipError_t e = gnngls::launch_tour_cost(tour, D, B, n, cost_out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "tour_cost");
 }
@@ -89,6 +110,7 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
     if (!W || !tour_out || B < 0 || n < 1 || depot < 0 || depot >= n)
         return fail(GNNGLS_ERR_ARG, "nearest_neighbor: bad argument");
     if (B == 0) return GNNGLS_OK;
+    ProfScope ps(GNNGLS_PROF_NEAREST_NEIGHBOR, (hipStream_t)stream);
     hipError_t e = gnngls::launch_nearest_neighbor(W, B, n, depot, tour_out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "nearest_neighbor");
 }
@@ -127,7 +149,11 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
         if (e != hipSuccess) return hip_fail(e, "gls_run: workspace memset");
         A.pen_ws = ws;
     }
-    hipError_t e = gnngls::launch_gls(A, tri, first_improvement != 0, st);
+    hipError_t e;
+    {
+        ProfScope ps(GNNGLS_PROF_GLS, st);
+        e = gnngls::launch_gls(A, tri, first_improvement != 0, st);
+    }
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
 }
@@ -185,20 +211,27 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     for (long b0 = 0; b0 < B; b0 += Bc) {
         const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
         const long M = (long)bc * N;
-        GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st));     // models.py:66
+        { ProfScope ps(GNNGLS_PROF_EMBED, st);
+        GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st)); }   // models.py:66
         for (int l = 0; l < n_layers; ++l) {                                                          // models.py:67-68
             const float *w = layers + (long)l * kLayerFloats;
             const float *fc_w = w, *attn_l = fc_w + 128L * 128, *attn_r = attn_l + 128;
             const float *bn1_s = attn_r + 128, *bn1_b = bn1_s + 128;
             const float *w1 = bn1_b + 128, *b1 = w1 + 512L * 128, *w2 = b1 + 512, *b2 = w2 + 128L * 512;
             const float *bn2_s = b2 + 128, *bn2_b = bn2_s + 128;
-            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st));
-            GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st));
-            GNNGLS_TRY(gnngls::launch_gat_combine(part, part_ms, h, bn1_s, bn1_b, h1, M, st));
-            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, h1, w1, hid, M, 512, 128, b1, nullptr, nullptr, nullptr, st));
-            GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_SKIP_BN, hid, w2, h, M, 128, 512, b2, h1, bn2_s, bn2_b, st));
+            { ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
+              GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
+            { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
+              GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
+            { ProfScope ps(GNNGLS_PROF_GAT_COMBINE, st);
+              GNNGLS_TRY(gnngls::launch_gat_combine(part, part_ms, h, bn1_s, bn1_b, h1, M, st)); }
+            { ProfScope ps(GNNGLS_PROF_GEMM_FFN1, st);
+              GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, h1, w1, hid, M, 512, 128, b1, nullptr, nullptr, nullptr, st)); }
+            { ProfScope ps(GNNGLS_PROF_GEMM_FFN2, st);
+              GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_SKIP_BN, hid, w2, h, M, 128, 512, b2, h1, bn2_s, bn2_b, st)); }
         }
-        GNNGLS_TRY(gnngls::launch_decision(h, dec_w, dec_b, y_out + b0 * N, M, st));                  // models.py:69
+        { ProfScope ps(GNNGLS_PROF_DECISION, st);
+          GNNGLS_TRY(gnngls::launch_decision(h, dec_w, dec_b, y_out + b0 * N, M, st)); }               // models.py:69
     }
 #undef GNNGLS_TRY
     return GNNGLS_OK;
@@ -207,6 +240,7 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
 int gnngls_pack_features(const double *D, int B, int n, double scale, double min_, float *feat, void *stream) {
     if (!D || !feat || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "pack_features: bad argument");
     if (B == 0) return GNNGLS_OK;
+    ProfScope ps(GNNGLS_PROF_PACK, (hipStream_t)stream);
     hipError_t e = gnngls::launch_pack_features(D, B, n, scale, min_, feat, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "pack_features");
 }
@@ -214,8 +248,39 @@ int gnngls_pack_features(const double *D, int B, int n, double scale, double min
 int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream) {
     if (!y || !out || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "unpack_regret: bad argument");
     if (B == 0) return GNNGLS_OK;
+    ProfScope ps(GNNGLS_PROF_UNPACK, (hipStream_t)stream);
     hipError_t e = gnngls::launch_unpack_regret(y, B, n, scale, min_, out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "unpack_regret");
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// per-kernel-class timing
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int gnngls_profile_enable(int on) {
+    for (auto &sp : g_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    g_spans.clear();
+    g_prof_on = on != 0;
+    return GNNGLS_OK;
+}
+
+int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind) {
+    if (!ms_by_kind || !launches_by_kind) return fail(GNNGLS_ERR_ARG, "profile_collect: bad argument");
+    for (int k = 0; k < GNNGLS_PROF_KINDS; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    for (auto &sp : g_spans) {
+        hipError_t e = hipEventSynchronize(sp.b);
+        if (e != hipSuccess) return hip_fail(e, "profile_collect");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, sp.a, sp.b);
+        if (e != hipSuccess) return hip_fail(e, "profile_collect");
+        ms_by_kind[sp.kind] += ms; launches_by_kind[sp.kind] += 1;
+        (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+    }
+    g_spans.clear();
+    return GNNGLS_OK;
 }
 
 }  // extern "C"

@@ -642,6 +642,7 @@ static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStr
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B), dim3(threads), lds, stream, A);
     return hipGetLastError();
 }
@@ -656,6 +657,7 @@ hipError_t launch_gls(const GlsArgs &A, bool tri, bool first_improvement, hipStr
 }
 
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(delta_all_kernel, dim3(B), dim3(256), 0, stream, tour, D, n, op, out);
     return hipGetLastError();
 }
@@ -664,6 +666,7 @@ hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, 
                             bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,
                             hipStream_t stream) {
     int threads = pos_i ? 64 : gls_block_threads(n);
+    (void)hipGetLastError();
     if (first_improvement)
         hipLaunchKernelGGL(best_move_kernel<true>, dim3(B), dim3(threads), 0, stream, tour, D, n, op, pos_i, delta_out, move_out, new_tour);
     else
@@ -672,12 +675,14 @@ hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, 
 }
 
 hipError_t launch_tour_cost(const int32_t *tour, const double *D, int B, int n, double *out, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(tour_cost_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, tour, D, B, n, out);
     return hipGetLastError();
 }
 
 hipError_t launch_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *tour_out, hipStream_t stream) {
     size_t lds = ((size_t)n + 15) & ~size_t(15);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(nearest_neighbor_kernel, dim3(B), dim3(64), lds, stream, W, n, depot, tour_out);
     return hipGetLastError();
 }

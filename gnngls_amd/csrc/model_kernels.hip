@@ -359,17 +359,20 @@ size_t gat_rows_lds_bytes(int n) {
 
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st) {
     long total = (long)B * (n * (n - 1) / 2);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(pack_features_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, D, B, n, scale, minv, feat);
     return hipGetLastError();
 }
 
 hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, double minv, double *out, hipStream_t st) {
     long total = (long)B * n * n;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(unpack_regret_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, y, B, n, scale, minv, out);
     return hipGetLastError();
 }
 
 hipError_t launch_embed(const float *x, const float *W, const float *b, float *h, long M, int in_dim, hipStream_t st) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(embed_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, x, W, b, h, M, in_dim);
     return hipGetLastError();
 }
@@ -377,12 +380,14 @@ hipError_t launch_embed(const float *x, const float *W, const float *b, float *h
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
                        const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st) {
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(N / BN));
-    if (epi == EPI_STORE)
+    (void)hipGetLastError();
+    if (epi == EPI_STORE) {
         hipLaunchKernelGGL(gemm_f32_kernel<EPI_STORE>, grid, dim3(256), 0, st, A, W, C, M, N, K, bias, skip, bn_scale, bn_shift);
-    else if (epi == EPI_BIAS_RELU)
+    } else if (epi == EPI_BIAS_RELU) {
         hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_RELU>, grid, dim3(256), 0, st, A, W, C, M, N, K, bias, skip, bn_scale, bn_shift);
-    else
+    } else {
         hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_SKIP_BN>, grid, dim3(256), 0, st, A, W, C, M, N, K, bias, skip, bn_scale, bn_shift);
+    }
     return hipGetLastError();
 }
 
@@ -392,17 +397,20 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gat_rows_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(256), lds, st, ft, attn_l, attn_r, n, part, part_ms);
     return hipGetLastError();
 }
 
 hipError_t launch_gat_combine(const float *part, const float *part_ms, const float *h, const float *bn_scale,
                               const float *bn_shift, float *out, long M, hipStream_t st) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(gat_combine_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, part, part_ms, h, bn_scale, bn_shift, out, M);
     return hipGetLastError();
 }
 
 hipError_t launch_decision(const float *h, const float *w, const float *b, float *y, long M, hipStream_t st) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(decision_kernel, dim3(grid_for(M, 8)), dim3(256), 0, st, h, w, b, y, M);
     return hipGetLastError();
 }

@@ -1,0 +1,136 @@
+"""Batched end-to-end hot path: the body of the reference's per-instance loop (scripts/test.py:59-104)
+for B independent instances at once, entirely on the GPU.
+
+    features (datasets.py:73-95) -> model forward (test.py:76-77) -> inverse scaler + clamp
+    (test.py:79-83) -> nearest_neighbor on the guide (test.py:85) -> tour_cost (test.py:90)
+    -> guided_local_search with the remaining budget (test.py:91-95)
+
+The 10 s budget of the reference starts before the forward pass (test.py:64), so the search gets
+`time_limit - elapsed`.  At most `gls_resident_capacity(n)` instances are searched concurrently (one
+persistent workgroup each); larger batches are processed in chunks, each with its own budget.
+"""
+import time
+from dataclasses import dataclass, field
+
+import torch
+
+from . import models as M
+from . import ops
+
+
+@dataclass
+class Scalers:
+    """MinMaxScaler parameters (sklearn: transform = x*scale_ + min_), datasets.py:48-51."""
+    feat_scale: float
+    feat_min: float
+    regret_scale: float = 1.0
+    regret_min: float = 0.0
+
+    @staticmethod
+    def from_sklearn(scalers):
+        if "edges" in scalers:            # backward compatibility, datasets.py:48-49
+            scalers = scalers["edges"]
+        f, r = scalers["features"], scalers["regret"]
+        return Scalers(float(f.scale_[0]), float(f.min_[0]), float(r.scale_[0]), float(r.min_[0]))
+
+    @staticmethod
+    def fit_weights(D):
+        """MinMax scaler fitted on the off-diagonal weights of a batch (synthetic substitute for
+        preprocess_dataset.py:39-48); regret scaler = identity (data_min 0, data_max 1)."""
+        n = D.shape[-1]
+        mask = ~torch.eye(n, dtype=torch.bool, device=D.device)
+        w = D[..., mask].float().double()
+        lo, hi = w.min().item(), w.max().item()
+        scale = 1.0 / (hi - lo)
+        return Scalers(scale, 0.0 - lo * scale, 1.0, 0.0)
+
+
+@dataclass
+class SolveResult:
+    best_tour: torch.Tensor
+    best_cost: torch.Tensor
+    init_cost: torch.Tensor
+    outer_iters: torch.Tensor
+    evals: torch.Tensor
+    moves: torch.Tensor
+    status: torch.Tensor
+    regret_pred: torch.Tensor = None
+    timing: dict = field(default_factory=dict)
+    trace_cost: torch.Tensor = None
+    trace_time: torch.Tensor = None
+
+
+def predict_regret(model, D, scalers):
+    """-> 'regret_pred' guide matrices [B,n,n] fp64 (test.py:72-83)."""
+    B, n, _ = D.shape
+    feat = M.pack_features(D, scalers.feat_scale, scalers.feat_min)
+    y = M.regret_forward(model, feat, B, n)
+    return M.unpack_regret(y, n, scalers.regret_scale, scalers.regret_min)
+
+
+def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit=10.0, perturbation_moves=20,
+                first_improvement=False, max_outer_iters=-1, trace_cap=0, want_trace_time=False, chunk=None,
+                keep_regret=False):
+    """D [B,n,n] fp64 CUDA tensor (symmetric).  Returns SolveResult with per-instance tensors."""
+    assert D.is_cuda and D.dtype == torch.float64
+    B, n, _ = D.shape
+    guides = list(guides)
+    need_model = "regret_pred" in guides
+    if need_model and (model is None or scalers is None):
+        raise ValueError("guide 'regret_pred' needs a model and scalers")
+    for g in guides:
+        if g not in ("regret_pred", "weight"):
+            raise ValueError(f"unknown guide {g!r}")
+    cap = ops.gls_resident_capacity(n)
+    if chunk is None:
+        chunk = cap if cap > 0 else 64
+    outs, timing = [], {"forward_s": 0.0, "init_s": 0.0, "search_s": 0.0, "chunks": 0}
+    for b0 in range(0, B, chunk):
+        Dc = D[b0:b0 + chunk].contiguous()
+        t0 = time.time()                                                   # test.py:64
+        R = None
+        if need_model:
+            R = predict_regret(model, Dc, scalers)
+            torch.cuda.synchronize()
+        t1 = time.time()
+        init = ops.nearest_neighbor(R if guides[0] == "regret_pred" else Dc)   # test.py:85-88
+        init_cost = ops.tour_cost(init, Dc)                                # test.py:90
+        gt = torch.stack([R if g == "regret_pred" else Dc for g in guides]).contiguous()
+        torch.cuda.synchronize()
+        t2 = time.time()
+        remaining = max(time_limit - (t2 - t0), 0.0)
+        r = ops.gls_run(Dc, gt, init, init_cost, perturbation_moves=perturbation_moves,
+                        first_improvement=first_improvement, max_outer_iters=max_outer_iters,
+                        time_limit_s=remaining, trace_cap=trace_cap, want_trace_time=want_trace_time)
+        torch.cuda.synchronize()
+        t3 = time.time()
+        timing["forward_s"] += t1 - t0
+        timing["init_s"] += t2 - t1
+        timing["search_s"] += t3 - t2
+        timing["chunks"] += 1
+        outs.append((r, init_cost, R if keep_regret else None))
+    cat = lambda xs: torch.cat(xs) if len(xs) > 1 else xs[0]  # noqa: E731
+    return SolveResult(
+        best_tour=cat([o[0].best_tour for o in outs]), best_cost=cat([o[0].best_cost for o in outs]),
+        init_cost=cat([o[1] for o in outs]), outer_iters=cat([o[0].outer_iters for o in outs]),
+        evals=cat([o[0].evals for o in outs]), moves=cat([o[0].trace_len for o in outs]),
+        status=cat([o[0].status for o in outs]),
+        regret_pred=cat([o[2] for o in outs]) if keep_regret and need_model else None, timing=timing,
+        trace_cost=cat([o[0].trace_cost for o in outs]) if trace_cap > 0 else None,
+        trace_time=cat([o[0].trace_time for o in outs]) if (trace_cap > 0 and want_trace_time) else None)
+
+
+def synthetic_model(seed=1234, device="cuda"):
+    """Seeded synthetic checkpoint with the reference architecture (embed 128, 8 heads, 8 layers --
+    models.py:59-61) and non-trivial BatchNorm statistics (the reference's checkpoints are LFS stubs)."""
+    torch.manual_seed(seed)
+    model = M.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
+                mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=g))
+                mod.weight.copy_(1.0 + 0.1 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+    return model.eval().to(device)

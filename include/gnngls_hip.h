@@ -136,6 +136,18 @@ int gnngls_pack_features(const double *D, int B, int n, double scale, double min
  * [B,n,n] matrix (zero diagonal) -- the 'regret_pred' guide of guided_local_search. */
 int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream);
 
+/* ---- measurement hooks (bench.py): per-kernel-class device time via HIP events recorded on the
+ * caller's stream around every launch made while profiling is enabled.  gnngls_profile_collect
+ * synchronises the recorded events, sums milliseconds and launch counts per class (arrays of
+ * GNNGLS_PROF_KINDS entries) and clears the log. */
+enum {
+    GNNGLS_PROF_PACK = 0, GNNGLS_PROF_EMBED, GNNGLS_PROF_GEMM_FC, GNNGLS_PROF_GAT_ROWS, GNNGLS_PROF_GAT_COMBINE,
+    GNNGLS_PROF_GEMM_FFN1, GNNGLS_PROF_GEMM_FFN2, GNNGLS_PROF_DECISION, GNNGLS_PROF_UNPACK,
+    GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_KINDS
+};
+int gnngls_profile_enable(int on);
+int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);
+
 #ifdef __cplusplus
 }
 #endif
