@@ -69,6 +69,10 @@ def load():
             raise GnnglsHipError(
                 f"{SO} not found: build the HIP extension with `python -m gnngls_amd.build` "
                 "(this package has no CPU fallback)")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  The process must
+        # hold exactly ONE HIP runtime, and it has to be the one torch's streams/allocations live in:
+        # import torch first so the dynamic linker binds this library to the runtime torch loaded.
+        import torch  # noqa: F401
         L = ctypes.CDLL(SO)
         for name, argtypes in SIGNATURES.items():
             f = getattr(L, name)      # AttributeError if the symbol is missing

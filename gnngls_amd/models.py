@@ -76,8 +76,8 @@ class GATConvParams(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         key = prefix + "bias"
-        if key in state_dict:
-            self.bias = state_dict.pop(key).detach().clone().float()
+        if key in state_dict and self.bias is None:
+            self.bias = torch.zeros_like(state_dict[key], dtype=torch.float32)   # then loaded like any buffer
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
