@@ -114,7 +114,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from gnngls_amd import _lib, ops, pipeline
+    from gnngls_amd import _lib, ops, parallel, pipeline
     from gnngls_amd.synthetic import random_instances
 
     n, B = args.n, args.batch
@@ -144,12 +144,7 @@ def main():
         best_known = torch.minimum(best_known, r.best_cost)
         local = torch.stack([r.best_cost, r.init_cost, r.outer_iters.double(), r.evals.double(),
                              r.status.double()], dim=1).contiguous()           # [B, 5] fp64
-        if world > 1:                                                          # the one collective of the path
-            bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-            dist.gather(local, bufs, dst=0)
-            gathered = torch.cat(bufs) if rank == 0 else None
-        else:
-            gathered = local
+        gathered = parallel.gather_results(local)                              # the one collective of the path
         return r
 
     for _ in range(args.warmup):

@@ -1,0 +1,34 @@
+"""Multi-GPU layout of the hot path: instances are independent (the reference's loop test.py:59-109
+carries no state across instances), so a batch is sharded into contiguous blocks, one process per
+GPU, with NO collective on the data path.  The only exchange is one gather of the per-instance
+results to rank 0 (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, world, rank):
+    """Contiguous block [lo, hi) of ceil(total/world) instances for `rank` (last ranks may be short)."""
+    per = (total + world - 1) // world
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total)
+
+
+def gather_results(local, dst=0):
+    """local [B_local, C] tensor on every rank -> concatenated [sum B_local, C] on rank `dst`, None
+    elsewhere.  Block sizes may differ between ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [int(s.item()) for s in all_sizes]
+    mx = max(all_sizes)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, all_sizes)])

@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+# coding: utf-8
+"""Drop-in for the reference's scripts/test.py (test.py:20-123): same positional arguments and flags,
+same per-instance semantics (10 s budget that starts before the forward pass, nearest-neighbour
+start on the guide, guided_local_search, gap vs the Concorde optimum stored in the instances) and
+the same DataFrame pickle (columns instance,time,opt_cost,cost,best_cost,gap,dt).
+
+The per-instance loop of the reference (test.py:59) is replaced by batches on the GPU: every instance
+of a batch gets the full --time_limit concurrently (gnngls_amd.pipeline.solve_batch).  `--use_gpu`
+is accepted for compatibility; this implementation always runs on the GPU and has no CPU path.
+"""
+import argparse
+import datetime
+import json
+import pathlib
+import sys
+import time
+import uuid
+
+import numpy as np
+import pandas as pd
+import torch
+import tqdm.auto as tqdm
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+
+import gnngls_amd  # noqa: E402
+from gnngls_amd import datasets, models, pipeline  # noqa: E402
+from gnngls_amd.algorithms import _attr_matrix  # noqa: E402
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(description='Test model')
+    parser.add_argument('data_path', type=pathlib.Path)
+    parser.add_argument('model_path', type=pathlib.Path)
+    parser.add_argument('run_dir', type=pathlib.Path)
+    parser.add_argument('guides', type=str, nargs='+')
+    parser.add_argument('--time_limit', type=float, default=10.)
+    parser.add_argument('--perturbation_moves', type=int, default=20)
+    parser.add_argument('--use_gpu', action='store_true')
+    parser.add_argument('--batch_size', type=int, default=0, help='instances searched concurrently (0 = device capacity)')
+    args = parser.parse_args()
+
+    params = json.load(open(args.model_path.parent / 'params.json'))
+    if 'efeat_drop_idx' in params:
+        test_set = datasets.TSPDataset(args.data_path, feat_drop_idx=params['efeat_drop_idx'])
+    else:
+        test_set = datasets.TSPDataset(args.data_path)
+
+    model, scalers = None, None
+    if 'regret_pred' in args.guides:
+        device = torch.device('cuda')
+        print('device =', device)
+        model = models.EdgePropertyPredictionModel(1, params['embed_dim'], 1, params['n_layers'],
+                                                   n_heads=params['n_heads']).to(device)
+        if datasets.is_lfs_pointer(args.model_path):
+            raise FileNotFoundError(f'{args.model_path} is a git-LFS pointer stub')
+        checkpoint = torch.load(args.model_path, map_location=device)
+        model.load_state_dict(checkpoint['model_state_dict'])
+        model.eval()
+        scalers = pipeline.Scalers.from_sklearn(test_set.scalers)
+
+    n = test_set.G.n
+    bs = args.batch_size or max(gnngls_amd.ops.gls_resident_capacity(n), 1)
+    gaps = []
+    search_progress = []
+    pbar = tqdm.tqdm(total=len(test_set.instances))
+    for b0 in range(0, len(test_set.instances), bs):
+        names = test_set.instances[b0:b0 + bs]
+        graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
+        opt_costs = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
+        D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
+        t = time.time()
+        for name, opt_cost in zip(names, opt_costs):
+            search_progress.append({'instance': name, 'time': t, 'opt_cost': opt_cost})
+        r = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
+                                 perturbation_moves=args.perturbation_moves, trace_cap=1 << 14, want_trace_time=True,
+                                 chunk=bs)
+        trace_len = r.moves.cpu().numpy()
+        trace_cost, trace_time = r.trace_cost.cpu().numpy(), r.trace_time.cpu().numpy()
+        for i, (name, opt_cost) in enumerate(zip(names, opt_costs)):
+            L = min(int(trace_len[i]), trace_cost.shape[1])
+            for c, dt_ in zip(trace_cost[i, :L], trace_time[i, :L]):
+                search_progress.append({'instance': name, 'opt_cost': opt_cost, 'time': t + float(dt_), 'cost': float(c)})
+            gaps.append((r.best_cost[i].item() / opt_cost - 1) * 100)
+        pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})
+        pbar.update(len(names))
+    pbar.close()
+
+    search_progress_df = pd.DataFrame.from_records(search_progress)
+    search_progress_df['best_cost'] = search_progress_df.groupby('instance')['cost'].cummin()
+    search_progress_df['gap'] = (search_progress_df['best_cost'] / search_progress_df['opt_cost'] - 1) * 100
+    search_progress_df['dt'] = search_progress_df['time'] - search_progress_df.groupby('instance')['time'].transform('min')
+
+    timestamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
+    run_name = f'{timestamp}_{uuid.uuid4().hex}.pkl'
+    if not args.run_dir.exists():
+        args.run_dir.mkdir()
+    search_progress_df.to_pickle(args.run_dir / run_name)

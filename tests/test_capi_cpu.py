@@ -1,0 +1,66 @@
+"""CPU checks of the boundary: the C-ABI library loads and exports every symbol include/gnngls_hip.h
+declares, host-side queries work without a GPU, and compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gnngls_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gnngls_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gnngls_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from gnngls_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    raw = ctypes.CDLL(_lib.SO)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/gnngls_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in gnngls_amd/_lib.py"
+
+
+def test_host_queries(lib):
+    assert lib.gnngls_abi_version() == 1
+    assert lib.gnngls_gls_resident_capacity(2) == 0
+    caps = [lib.gnngls_gls_resident_capacity(n) for n in (20, 50, 100, 150)]
+    assert all(c > 0 for c in caps) and caps == sorted(caps, reverse=True)
+    assert lib.gnngls_gls_resident_capacity(400) == 0            # triangles exceed 160 KiB of LDS
+    n_layers = 8
+    per_layer = 128 * 128 + 4 * 128 + 512 * 128 + 512 + 128 * 512 + 3 * 128
+    assert lib.gnngls_model_packed_floats(1, n_layers) == 128 + 128 + n_layers * per_layer + 128 + 4
+    assert lib.gnngls_regret_forward_workspace_bytes(2, 100) > 2 * 4950 * 128 * 4 * 9
+
+
+def test_bad_arguments_are_rejected(lib):
+    from gnngls_amd import _lib
+    assert lib.gnngls_tour_cost(None, None, 1, 5, None, None) == -1
+    assert b"tour_cost" in lib.gnngls_last_error()
+    with pytest.raises(_lib.GnnglsHipError):
+        _lib.check(lib.gnngls_gls_run(None, None, 0, 1, 5, None, None, 20, 0, 0, 0.0, 1.0, None, None, None, None, None,
+                                      0, None, None, None, None, None), "gls_run")
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gnngls_amd import _lib, ops
+    with pytest.raises(_lib.GnnglsHipError):
+        ops.as_dev([[0, 1, 0]], torch.int32)
+    from gnngls_amd.models import EdgePropertyPredictionModel, LineGraph
+    m = EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8).eval()
+    with pytest.raises(_lib.GnnglsHipError):
+        m(LineGraph(4), torch.zeros(6, 1))

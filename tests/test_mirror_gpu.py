@@ -1,0 +1,154 @@
+"""GPU tests of the reference-signature mirrors (gnngls_amd.operators / algorithms) and of the
+test.py-compatible CLI.  Same call forms as the reference, results compared with the golden vectors
+captured from the reference (bit exact)."""
+import glob
+import itertools
+import json
+import os
+import pickle
+import subprocess
+import sys
+import time
+
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fbits(x):
+    return np.float64(x).tobytes()
+
+
+def graph_from_matrix(D, **extra):
+    n = D.shape[0]
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    for i, j in itertools.combinations(range(n), 2):
+        G.add_edge(i, j, weight=np.float64(D[i, j]), **{k: np.float64(v[i, j]) for k, v in extra.items()})
+    return G
+
+
+def test_operators_mirror_golden():
+    from gnngls_amd import operators as ops
+    g = np.load(os.path.join(GOLD, "ops_n20.npz"))
+    tour, D = g["tour"].tolist(), g["D"]
+    n = len(tour) - 1
+    assert fbits(ops.two_opt_cost(tour, D, 3, 9)) == fbits(g["two_opt_table"][3, 9])
+    assert fbits(ops.relocate_cost(tour, D, 11, 2)) == fbits(g["relocate_table"][11, 2])
+    assert ops.two_opt_cost(tour, D, 4, 4) == 0 and ops.relocate_cost(tour, D, 4, 4) == 0
+    for fi in (False, True):
+        for name in ("two_opt_a2a", "relocate_a2a"):
+            d, t = getattr(ops, name)(tour, D, fi)
+            assert fbits(d) == fbits(g[f"{name}_fi{int(fi)}_delta"]) and t == g[f"{name}_fi{int(fi)}_tour"].tolist()
+        for name in ("two_opt_o2a", "relocate_o2a"):
+            for i in (1, 7, n - 1):
+                d, t = getattr(ops, name)(tour, D, i, fi)
+                assert fbits(d) == fbits(g[f"{name}_fi{int(fi)}_delta"][i - 1])
+                assert t == g[f"{name}_fi{int(fi)}_tour"][i - 1].tolist()
+    with pytest.raises(AssertionError):                         # operators.py:54,107
+        ops.two_opt_o2a(tour, D, 0)
+    with pytest.raises(AssertionError):
+        ops.relocate_o2a(tour, D, n)
+    assert tour == g["tour"].tolist()                           # inputs never mutated
+
+
+def test_algorithms_mirror_golden():
+    from gnngls_amd import algorithms as alg
+    g = np.load(os.path.join(GOLD, "ls_n50.npz"))
+    t, c, prog = alg.local_search(g["fi0_init_tour"].tolist(), float(g["fi0_init_cost"]), g["D"], False)
+    assert t == g["fi0_tour"].tolist() and fbits(c) == fbits(g["fi0_cost"])
+    assert [fbits(r["cost"]) for r in prog] == [fbits(x) for x in g["fi0_trace"]]
+    assert all(set(r) == {"time", "cost"} for r in prog)
+    g = np.load(os.path.join(GOLD, "misc.npz"))
+    G = graph_from_matrix(g["nn_W_weight"], regret_pred=g["nn_W_regret"])
+    assert alg.nearest_neighbor(G, 0, weight="regret_pred") == g["nn_tour_regret"].tolist()
+    assert alg.nearest_neighbor(G, 0) == g["nn_tour_weight"].tolist()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "gls_c[125]_*.npz"))), ids=os.path.basename)
+def test_guided_local_search_mirror_golden(path):
+    from gnngls_amd import algorithms as alg
+    g = np.load(path)
+    names = [str(x) for x in g["guide_names"]]
+    extra = {nm: g["guides"][k] for k, nm in enumerate(names) if nm != "weight"}
+    G = graph_from_matrix(g["D"], **extra)
+    best_tour, best_cost, prog = alg.guided_local_search(
+        G, g["init_tour"].tolist(), float(g["init_cost"]), time.time() + 1000, weight="weight", guides=names,
+        perturbation_moves=int(g["perturbation_moves"]), first_improvement=bool(g["first_improvement"]),
+        max_outer_iters=int(g["K"]))
+    assert best_tour == g["best_tour"].tolist() and fbits(best_cost) == fbits(g["best_cost"])
+    assert [fbits(r["cost"]) for r in prog] == [fbits(x) for x in g["trace"]]
+    pen = np.asarray(nx.attr_matrix(G, "penalty")[0])           # G is mutated like the reference (algorithms.py:138,161)
+    assert np.array_equal(pen.astype(np.int32), g["penalty"])
+
+
+def test_guided_local_search_mirror_deadline():
+    """t_lim is an absolute deadline (algorithms.py:146)."""
+    from gnngls_amd import algorithms as alg
+    import gnngls_amd
+    rng = np.random.default_rng(0)
+    pos = rng.random((30, 2))
+    D = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+    G = graph_from_matrix(D)
+    init = alg.nearest_neighbor(G, 0)
+    t0 = time.time()
+    best_tour, best_cost, prog = alg.guided_local_search(G, init, gnngls_amd.tour_cost(G, init), t0 + 0.5,
+                                                         perturbation_moves=20)
+    assert 0.4 < time.time() - t0 < 5.0
+    assert gnngls_amd.is_valid_tour(G, best_tour)
+    assert best_cost == pytest.approx(gnngls_amd.tour_cost(G, best_tour), rel=1e-12)
+    assert min(r["cost"] for r in prog) == best_cost and prog[-1]["time"] <= t0 + 5.0
+
+
+def test_cli_end_to_end(tmp_path):
+    """scripts/test.py with the reference's arguments on a tiny synthetic dataset + checkpoint."""
+    from sklearn.preprocessing import MinMaxScaler
+
+    from gnngls_amd import datasets
+    from gnngls_amd.models import EdgePropertyPredictionModel
+    rng = np.random.default_rng(5)
+    data = tmp_path / "tsp12"
+    data.mkdir()
+    scalers = {"features": MinMaxScaler(), "regret": MinMaxScaler()}
+    names = []
+    for k in range(5):
+        pos = rng.random((12, 2))
+        G = nx.Graph()
+        for v, p in enumerate(pos):
+            G.add_node(v, pos=p)
+        for i, j in itertools.combinations(G.nodes, 2):
+            G.add_edge(i, j, weight=np.linalg.norm(pos[j] - pos[i]), in_solution=False, regret=float(rng.random()))
+        for v in range(12):                                      # a Hamiltonian cycle marked as "the solution"
+            G.edges[v, (v + 1) % 12]["in_solution"] = True
+        datasets.set_features(G)
+        for key in scalers:
+            scalers[key].partial_fit(np.vstack([G.edges[e][key] for e in G.edges]))
+        pickle.dump(G, open(data / f"i{k}.pkl", "wb"))
+        names.append(f"i{k}.pkl")
+    (data / "test.txt").write_text("\n".join(names) + "\n")
+    pickle.dump(scalers, open(data / "scalers.pkl", "wb"))
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    torch.manual_seed(0)
+    model = EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+    torch.save({"epoch": 0, "model_state_dict": model.state_dict()}, mdir / "checkpoint_best_val.pt")
+    json.dump({"embed_dim": 128, "n_layers": 3, "n_heads": 8}, open(mdir / "params.json", "w"))
+    run_dir = tmp_path / "runs"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "test.py"), str(data / "test.txt"),
+           str(mdir / "checkpoint_best_val.pt"), str(run_dir), "regret_pred", "weight", "--time_limit", "0.3",
+           "--perturbation_moves", "10", "--use_gpu"]
+    subprocess.check_call(cmd, cwd=ROOT)
+    out = list(run_dir.glob("*.pkl"))
+    assert len(out) == 1
+    df = pickle.load(open(out[0], "rb"))
+    assert set(["instance", "time", "opt_cost", "cost", "best_cost", "gap", "dt"]) <= set(df.columns)
+    assert sorted(df["instance"].unique()) == names
+    last = df.dropna(subset=["cost"]).groupby("instance").tail(1)
+    assert (last["gap"] < 0).all()          # the marked cycle 0-1-..-11 is far from optimal: search beats it
+    assert (df["dt"] >= 0).all() and (df["dt"] < 5).all()
