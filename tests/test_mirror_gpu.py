@@ -103,7 +103,9 @@ def test_guided_local_search_mirror_deadline():
     assert 0.4 < time.time() - t0 < 5.0
     assert gnngls_amd.is_valid_tour(G, best_tour)
     assert best_cost == pytest.approx(gnngls_amd.tour_cost(G, best_tour), rel=1e-12)
-    assert min(r["cost"] for r in prog) == best_cost and prog[-1]["time"] <= t0 + 5.0
+    # best is only updated after a descent (algorithms.py:190-191) with the incrementally updated cost, while
+    # perturbation moves log tour_cost() recomputed from scratch: equal up to fp64 rounding, not bitwise
+    assert min(r["cost"] for r in prog) == pytest.approx(best_cost, rel=1e-12) and prog[-1]["time"] <= t0 + 5.0
 
 
 def test_cli_end_to_end(tmp_path):
