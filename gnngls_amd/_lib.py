@@ -23,13 +23,14 @@ SIGNATURES = {
     "gnngls_best_move": [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp],
     "gnngls_tour_cost": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_nearest_neighbor": [_vp, _int, _int, _int, _vp, _vp],
-    "gnngls_gls_run": [_vp, _vp, _int, _int, _int, _vp, _vp, _int, _int, _i64, _f64, _f64,
+    "gnngls_gls_run": [_vp, _vp, _int, _int, _int, _vp, _vp, _int, _int, _int, _i64, _f64, _f64,
                        _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
     "gnngls_model_packed_floats": [_int, _int],
     "gnngls_regret_forward_workspace_bytes": [_int, _int],
     "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
     "gnngls_pack_features": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
+    "gnngls_debug_set_penalty16_limit": [_int],
     "gnngls_profile_enable": [_int],
     "gnngls_profile_collect": [_vp, _vp],
 }

@@ -45,6 +45,8 @@ struct ProfScope {
     }
 };
 
+int g_pen16_limit = 65535;
+
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr int kMaxWavesPerCU = 32;
 
@@ -57,7 +59,27 @@ int num_cus() {
     return 256;   // MI355X
 }
 
-bool tri_fits(int n) { return gnngls::gls_lds_bytes(n, true) <= kLdsPerCU; }
+// Storage configuration of the persistent search kernel for instances of n nodes: the one with the
+// most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
+struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; };
+
+GlsConfig gls_config(int n, int requested_bits) {
+    const int threads = gnngls::gls_block_threads(n);
+    const int by_waves = kMaxWavesPerCU / (threads / 64);
+    GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, threads, gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0};
+    bool have = false;
+    auto consider = [&](int store, int bits) {
+        size_t lds = gnngls::gls_lds_bytes(n, store, bits);
+        if (lds > kLdsPerCU) return;
+        int per_cu = (int)(kLdsPerCU / lds);
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }
+    };
+    if (requested_bits == 0 || requested_bits == 32) consider(gnngls::GLS_STORE_TRI, 32);
+    if (requested_bits == 0 || requested_bits == 16) consider(gnngls::GLS_STORE_TRI, 16);
+    if (requested_bits == 0 && n <= 255) consider(gnngls::GLS_STORE_COMPACT, 32);
+    return pick;
+}
 }  // namespace
 
 extern "C" {
@@ -66,12 +88,10 @@ int gnngls_abi_version(void) { return 1; }
 const char *gnngls_last_error(void) { return g_err; }
 
 int gnngls_gls_resident_capacity(int n) {
-    if (n < 3 || !tri_fits(n)) return 0;
-    size_t lds = gnngls::gls_lds_bytes(n, true);
-    int by_lds = (int)(kLdsPerCU / lds);
-    int by_waves = kMaxWavesPerCU / (gnngls::gls_block_threads(n) / 64);
-    int per_cu = by_lds < by_waves ? by_lds : by_waves;
-    return per_cu * num_cus();
+    if (n < 3) return 0;
+    GlsConfig c = gls_config(n, 0);
+    if (c.store == gnngls::GLS_STORE_GLOBAL) return 0;
+    return c.per_cu * num_cus();
 }
 
 int gnngls_two_opt_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream) {
@@ -117,7 +137,7 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
 
 int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, int n,
                    const int32_t *init_tour, const double *init_cost,
-                   int perturbation_moves, int first_improvement,
+                   int perturbation_moves, int first_improvement, int penalty_bits,
                    int64_t max_outer_iters, double time_limit_s, double watchdog_s,
                    int32_t *best_tour, double *best_cost, int64_t *outer_iters,
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
@@ -127,6 +147,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (max_outer_iters != 0 && (!guides || n_guides < 1))
         return fail(GNNGLS_ERR_ARG, "gls_run: guides required when outer iterations are requested");
     if (!(watchdog_s > 0.0)) return fail(GNNGLS_ERR_ARG, "gls_run: watchdog_s must be > 0");
+    if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32)
+        return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16 or 32");
     if (B == 0) return GNNGLS_OK;
     hipStream_t st = (hipStream_t)stream;
     gnngls::GlsArgs A;
@@ -137,12 +159,15 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.max_outer_iters = max_outer_iters; A.time_limit_s = time_limit_s; A.watchdog_s = watchdog_s;
     A.best_tour = best_tour; A.best_cost = best_cost; A.outer_iters = (long long *)outer_iters;
     A.trace_cost = trace_cost; A.trace_time = trace_time; A.trace_cap = trace_cost ? trace_cap : 0;
+    A.pen16_limit = g_pen16_limit;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
-    bool tri = tri_fits(n);
+    const GlsConfig cfg = gls_config(n, penalty_bits);
     int32_t *ws = nullptr;
-    if (!tri) {
-        // global-memory fallback for instances whose triangles exceed LDS: penalties in a zeroed workspace
-        size_t bytes = (size_t)B * n * n * sizeof(int32_t);
+    if (cfg.store != gnngls::GLS_STORE_TRI) {
+        // penalties in global memory (zeroed workspace): full matrices for the global store, packed
+        // triangles for the compact store
+        size_t per = cfg.store == gnngls::GLS_STORE_GLOBAL ? (size_t)n * n : (size_t)n * (n - 1) / 2;
+        size_t bytes = (size_t)B * per * sizeof(int32_t);
         hipError_t e = hipMallocAsync((void **)&ws, bytes, st);
         if (e != hipSuccess) return hip_fail(e, "gls_run: workspace alloc");
         e = hipMemsetAsync(ws, 0, bytes, st);
@@ -152,7 +177,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     hipError_t e;
     {
         ProfScope ps(GNNGLS_PROF_GLS, st);
-        e = gnngls::launch_gls(A, tri, first_improvement != 0, st);
+        e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, first_improvement != 0, st);
     }
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
@@ -259,6 +284,12 @@ int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_
 // per-kernel-class timing
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+
+int gnngls_debug_set_penalty16_limit(int limit) {
+    if (limit < 1 || limit > 65535) return fail(GNNGLS_ERR_ARG, "penalty16 limit must be in 1..65535");
+    g_pen16_limit = limit;
+    return GNNGLS_OK;
+}
 
 int gnngls_profile_enable(int on) {
     for (auto &sp : g_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define GNNGLS_STATUS_WATCHDOG_DEV 1
+#define GNNGLS_STATUS_PENALTY_OVERFLOW_DEV 2
 
 namespace gnngls {
 
@@ -26,12 +27,15 @@ struct GlsArgs {
     int32_t *penalty_out;
     long long *evals;
     int32_t *status;
-    int32_t *pen_ws;           // global-store mode only: [B,n,n] int32, zeroed by the host
+    int32_t *pen_ws;           // global store: [B,n,n] int32; compact store: [B,n(n-1)/2] int32; zeroed by the host
+    int pen16_limit;           // 65535 (see gnngls_debug_set_penalty16_limit)
 };
 
-size_t gls_lds_bytes(int n, bool tri);
+enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
+size_t gls_lds_bytes(int n, int store, int penalty_bits);
 int gls_block_threads(int n);
-hipError_t launch_gls(const GlsArgs &A, bool tri, bool first_improvement, hipStream_t stream);
+hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
+                      hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
                             bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,

@@ -36,6 +36,7 @@ namespace gnngls {
 
 constexpr int kWave = 64;
 constexpr int kNoKey = INT_MAX;
+constexpr int kGuidePasses = 4;   // register-cached guide values cover n <= 256
 
 __device__ __forceinline__ int make_key(int i, int j) { return (i << 16) | j; }
 
@@ -52,17 +53,58 @@ __device__ __forceinline__ bool close_to_zero(double delta) {
 // ---------------------------------------------------------------------------------------------
 // Packed lower triangle without diagonal (symmetric D only).  The diagonal is never read by a
 // valid move evaluation for n >= 3 (all four/six endpoints are distinct nodes).
+// PT = penalty element type in LDS: int32_t, or uint16_t (half the footprint -> one more resident
+// workgroup per CU at n=100); a 16-bit counter that would pass 65535 aborts the instance with
+// GNNGLS_STATUS_PENALTY_OVERFLOW_DEV and the host reruns it with 32-bit counters.
+template <class PT>
 struct TriStore {
     const double *d;   // LDS
-    int32_t *p;        // LDS
+    PT *p;             // LDS
+    using pen_t = PT;
+    using tour_t = int32_t;
     static constexpr bool kSymmetric = true;
+    static constexpr bool kPenInLds = true;
+    static constexpr int kWavesPerSimd = 6;      // 3 workgroups of 8 waves per CU
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
         return ((hi * (hi - 1)) >> 1) + lo;
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
-    __device__ __forceinline__ int pen(int a, int b) const { return p[idx(a, b)]; }
-    __device__ __forceinline__ void pen_inc(int a, int b) const { p[idx(a, b)] += 1; }
+    __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
+    int limit;         // largest representable count (65535 for 16-bit counters; lowered only by the test hook)
+    __device__ __forceinline__ bool pen_inc(int a, int b) const {     // true = counter overflow
+        const int q = idx(a, b);
+        const PT v = p[q];
+        if (sizeof(PT) == 2 && (int)v >= limit) return true;
+        p[q] = (PT)(v + 1);
+        return false;
+    }
+};
+
+// Compact store: only the fp64 distance triangle is LDS-resident (n=100: 39.6 KB, with byte-sized tour
+// arrays exactly 40 KiB per workgroup -> FOUR resident workgroups per CU); the penalty triangle
+// lives in global memory (int32, L2-resident: 19.8 KB per instance) and is accessed with agent-scope
+// relaxed atomics (sc1 loads / L2 atomic add), which are coherent without any cache maintenance.
+struct TriDGlobalP {
+    const double *d;   // LDS
+    int32_t *p;        // global, packed triangle
+    using pen_t = int32_t;
+    using tour_t = uint8_t;                       // n <= 255
+    static constexpr bool kSymmetric = true;
+    static constexpr bool kPenInLds = false;
+    static constexpr int kWavesPerSimd = 8;      // 4 workgroups of 8 waves per CU
+    __device__ __forceinline__ static int idx(int a, int b) {
+        int hi = a > b ? a : b, lo = a > b ? b : a;
+        return ((hi * (hi - 1)) >> 1) + lo;
+    }
+    __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
+    __device__ __forceinline__ int pen(int a, int b) const {
+        return __hip_atomic_load(p + idx(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ bool pen_inc(int a, int b) const {
+        (void)__hip_atomic_fetch_add(p + idx(a, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
 };
 
 // Full row-major matrices in global memory (any n, asymmetric D allowed: index order follows the
@@ -74,9 +116,14 @@ struct GlobalStore {
     static constexpr bool kSymmetric = false;
     __device__ __forceinline__ double dist(int a, int b) const { return d[(size_t)a * n + b]; }
     __device__ __forceinline__ int pen(int a, int b) const { return p[(size_t)a * n + b]; }
-    __device__ __forceinline__ void pen_inc(int a, int b) const {
+    using pen_t = int32_t;
+    using tour_t = int32_t;
+    static constexpr bool kPenInLds = false;
+    static constexpr int kWavesPerSimd = 4;
+    __device__ __forceinline__ bool pen_inc(int a, int b) const {
         p[(size_t)a * n + b] += 1;
         p[(size_t)b * n + a] += 1;
+        return false;
     }
 };
 
@@ -100,8 +147,8 @@ struct GuidedDist {
 // ---------------------------------------------------------------------------------------------
 // Move evaluation, reference operand order   [exact]
 // ---------------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ double two_opt_cost(const int32_t *t, const F &f, int i, int j) {
+template <class TT, class F>
+__device__ __forceinline__ double two_opt_cost(const TT *t, const F &f, int i, int j) {
     if (i == j) return 0.0;
     if (j < i) { int x = i; i = j; j = x; }
     int a = t[i], b = t[i - 1], c = t[j], d = t[j - 1];
@@ -111,8 +158,8 @@ __device__ __forceinline__ double two_opt_cost(const int32_t *t, const F &f, int
     return delta;
 }
 
-template <class F>
-__device__ __forceinline__ double relocate_cost(const int32_t *t, const F &f, int i, int j) {
+template <class TT, class F>
+__device__ __forceinline__ double relocate_cost(const TT *t, const F &f, int i, int j) {
     if (i == j) return 0.0;
     int a = t[i - 1], b = t[i], c = t[i + 1];
     int d, e;
@@ -162,14 +209,75 @@ __device__ __forceinline__ void consider(double delta, int key, double &bd, int 
     if (delta < 0.0 && better<FI>(delta, key, bd, bk) && !close_to_zero(delta)) { bd = delta; bk = key; }
 }
 
+// ---- wavefront reductions on DPP (no LDS crossbar round trips) ---------------------------------
+// Inclusive min-scan inside each row of 16 lanes (row_shr 1,2,4,8), then row_bcast15 / row_bcast31
+// carry the row results upwards; lane 63 ends up with the minimum of all 64 lanes (the gfx9
+// wave64 reduction sequence), read back with v_readlane into an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umin_step(unsigned x) {
+    unsigned y = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, CTRL, ROW_MASK, 0xf, false);
+    return y < x ? y : x;
+}
+__device__ __forceinline__ unsigned wave_umin(unsigned x) {
+    x = dpp_umin_step<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_umin_step<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_umin_step<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_umin_step<0x118, 0xf>(x);   // row_shr:8
+    x = dpp_umin_step<0x142, 0xa>(x);   // row_bcast:15 -> rows 1,3
+    x = dpp_umin_step<0x143, 0xc>(x);   // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// order-preserving map fp64 -> uint64 (a < b  <=>  key(a) < key(b), for non-NaN values)
+__device__ __forceinline__ unsigned long long sortable(double v) {
+    v = (v == 0.0) ? 0.0 : v;            // -0.0 and +0.0 compare equal: give them one key
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unsortable(unsigned long long k) {
+    unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// lexicographic wave-wide min of (value, key): three 32-bit DPP reductions; result uniform in all lanes
+__device__ __forceinline__ void wave_min_value_key(double &d, int &k) {
+    const unsigned long long sk = sortable(d);
+    const unsigned hi = (unsigned)(sk >> 32), lo = (unsigned)sk;
+    const unsigned mhi = wave_umin(hi);
+    const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
+    const unsigned mk = wave_umin((hi == mhi && lo == mlo) ? (unsigned)k : 0x7fffffffu);
+    d = unsortable(((unsigned long long)mhi << 32) | mlo);
+    k = (int)mk;
+}
+
 template <bool FI>
 __device__ __forceinline__ void wave_reduce_best(double &d, int &k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        double od = __shfl_xor(d, off, kWave);
-        int ok = __shfl_xor(k, off, kWave);
-        if (better<FI>(od, ok, d, k)) { d = od; k = ok; }
+    if (FI) {
+        // first improvement: smallest key among the candidates; its delta is fetched from the owning lane
+        const unsigned mk = wave_umin((unsigned)k);
+        const unsigned long long own = __ballot((unsigned)k == mk);
+        const int src = __ffsll((long long)own) - 1;
+        const long long bits = __double_as_longlong(d);
+        const int lo = __builtin_amdgcn_readlane((int)bits, src);
+        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+        d = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        k = (int)mk;
+    } else {
+        wave_min_value_key(d, k);
     }
+}
+
+// arg-max with "first maximum wins": min over (-value order, position)
+__device__ __forceinline__ void wave_argmax_first(double &v, int &pos) {
+    // lanes without a candidate carry pos == kNoKey and must lose: give them the largest key
+    unsigned long long sk = ~sortable(v);
+    if (pos == kNoKey) sk = ~0ull;
+    const unsigned hi = (unsigned)(sk >> 32), lo = (unsigned)sk;
+    const unsigned mhi = wave_umin(hi);
+    const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
+    const unsigned mp = wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
+    v = unsortable(~(((unsigned long long)mhi << 32) | mlo));
+    pos = (int)mp;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -179,8 +287,8 @@ __device__ __forceinline__ void wave_sync() {
 
 // LDS control block shared by the workgroup
 struct Ctl {
-    double red_d[2][16];
-    int red_k[2][16];
+    double red_d[2][8];
+    int red_k[2][8];
     double cost;
     int flag;
     int pad;
@@ -204,8 +312,8 @@ __device__ __forceinline__ void block_reduce_best(Ctl *ctl, int &phase, int wave
 // ---------------------------------------------------------------------------------------------
 // a2a scans on the plain matrix.  Ef[p] = dist(t[p-1], t[p]), Eb[p] = dist(t[p], t[p-1]), p=1..n.
 // ---------------------------------------------------------------------------------------------
-template <class S, bool FI>
-__device__ __forceinline__ void scan_two_opt_a2a(const S &s, const int32_t *t, const double *Eb, int n,
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_two_opt_a2a(const S &s, const TT *t, const double *Eb, int n,
                                                  int wave, int nwaves, int lane, double &bd, int &bk) {
     // itertools.combinations(range(1,n),2), |i-j| >= 2  (operators.py:36-39)
     for (int i = 1 + wave; i <= n - 3; i += nwaves) {
@@ -221,8 +329,8 @@ __device__ __forceinline__ void scan_two_opt_a2a(const S &s, const int32_t *t, c
     }
 }
 
-template <class S, bool FI>
-__device__ __forceinline__ void scan_relocate_a2a(const S &s, const int32_t *t, const double *Ef, int n,
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_relocate_a2a(const S &s, const TT *t, const double *Ef, int n,
                                                   int wave, int nwaves, int lane, double &bd, int &bk) {
     // itertools.permutations(range(1,n),2), skip i-j == 1  (operators.py:133-136)
     for (int i = 1 + wave; i <= n - 1; i += nwaves) {
@@ -244,8 +352,8 @@ __device__ __forceinline__ void scan_relocate_a2a(const S &s, const int32_t *t, 
 }
 
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
-template <class F, bool FI>
-__device__ __forceinline__ void scan_two_opt_o2a(const int32_t *t, const F &f, int n, int i,
+template <class F, bool FI, class TT>
+__device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
                                                  int tid, int nthr, double &bd, int &bk) {
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         int dj = i - j; if (dj < 0) dj = -dj;
@@ -253,8 +361,8 @@ __device__ __forceinline__ void scan_two_opt_o2a(const int32_t *t, const F &f, i
         consider<FI>(two_opt_cost(t, f, i, j), j, bd, bk);
     }
 }
-template <class F, bool FI>
-__device__ __forceinline__ void scan_relocate_o2a(const int32_t *t, const F &f, int n, int i,
+template <class F, bool FI, class TT>
+__device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n, int i,
                                                   int tid, int nthr, double &bd, int &bk) {
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         if (j == i) continue;                                // operators.py:114-115
@@ -263,12 +371,12 @@ __device__ __forceinline__ void scan_relocate_o2a(const int32_t *t, const F &f, 
 }
 
 // new tour + edge arrays in one pass; caller synchronises afterwards.
-template <class S>
-__device__ __forceinline__ void apply_move(const S &s, const int32_t *told, int32_t *tnew, double *Ef, double *Eb,
+template <class S, class TT>
+__device__ __forceinline__ void apply_move(const S &s, const TT *told, TT *tnew, double *Ef, double *Eb,
                                            int n, int op, int i, int j, int tid, int nthr, bool want_edges) {
     for (int p = tid; p <= n; p += nthr) {
         int np = told[move_src(op, p, i, j)];
-        tnew[p] = np;
+        tnew[p] = (TT)np;
         if (want_edges && p >= 1) {
             int nq = told[move_src(op, p - 1, i, j)];
             Ef[p] = s.dist(nq, np);
@@ -277,8 +385,8 @@ __device__ __forceinline__ void apply_move(const S &s, const int32_t *told, int3
     }
 }
 
-template <class S>
-__device__ __forceinline__ void build_edges(const S &s, const int32_t *t, double *Ef, double *Eb, int n,
+template <class S, class TT>
+__device__ __forceinline__ void build_edges(const S &s, const TT *t, double *Ef, double *Eb, int n,
                                             int tid, int nthr) {
     for (int p = 1 + tid; p <= n; p += nthr) {
         int u = t[p - 1], v = t[p];
@@ -308,8 +416,8 @@ struct Trace {
     }
 };
 
-template <class S, bool FI>
-__device__ void local_search_dev(const S &s, int32_t *&t, int32_t *&t2, double *Ef, double *Eb, int n,
+template <class S, bool FI, class TT>
+__device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, Trace &tr, long long &evals) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
@@ -329,7 +437,7 @@ __device__ void local_search_dev(const S &s, int32_t *&t, int32_t *&t2, double *
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
                 apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true);
-                int32_t *x = t; t = t2; t2 = x;
+                TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();
             }
@@ -337,8 +445,10 @@ __device__ void local_search_dev(const S &s, int32_t *&t, int32_t *&t2, double *
     }
 }
 
+// launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
+// CU at n=100 need <= 80 VGPRs), 4 for the global-memory fallback.
 template <class S, bool FI>
-__global__ void gls_kernel(GlsArgs A) {
+__global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int n = A.n;
@@ -353,27 +463,34 @@ __global__ void gls_kernel(GlsArgs A) {
     double *Ef = reinterpret_cast<double *>(smem + off);       off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15);
     double *Eb = Ef;
     if (!S::kSymmetric) { Eb = reinterpret_cast<double *>(smem + off); off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15); }
-    int32_t *t = reinterpret_cast<int32_t *>(smem + off);      off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
-    int32_t *t2 = reinterpret_cast<int32_t *>(smem + off);     off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
-    int32_t *bt = reinterpret_cast<int32_t *>(smem + off);     off += ((size_t)(n + 1) * 4 + 15) & ~size_t(15);
+    using TT = typename S::tour_t;
+    TT *t = reinterpret_cast<TT *>(smem + off);                off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
+    TT *t2 = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
+    TT *bt = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
 
     S s;
     if constexpr (S::kSymmetric) {
         const int ntri = n * (n - 1) / 2;
         double *dtri = reinterpret_cast<double *>(smem + off);   off += ((size_t)ntri * 8 + 15) & ~size_t(15);
-        int32_t *ptri = reinterpret_cast<int32_t *>(smem + off);
         // row a of the lower triangle is contiguous in both the source row and the packed image
         for (int a = 1 + wave; a < n; a += (nthr >> 6)) {
             const double *src = Dg + (size_t)a * n;
             double *dst = dtri + ((a * (a - 1)) >> 1);
             for (int c = lane; c < a; c += kWave) dst[c] = src[c];
         }
-        for (int q = tid; q < ntri; q += nthr) ptri[q] = 0;                  // algorithms.py:138
-        s.d = dtri; s.p = ptri;
+        s.d = dtri;
+        if constexpr (S::kPenInLds) {
+            using PT = typename S::pen_t;
+            PT *ptri = reinterpret_cast<PT *>(smem + off);
+            for (int q = tid; q < ntri; q += nthr) ptri[q] = (PT)0;          // algorithms.py:138
+            s.p = ptri; s.limit = A.pen16_limit;
+        } else {
+            s.p = A.pen_ws + (size_t)b * ntri;                                // zeroed by the host
+        }
     } else {
         s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host
     }
-    for (int p = tid; p <= n; p += nthr) { int v = A.init_tour[(size_t)b * (n + 1) + p]; t[p] = v; bt[p] = v; }
+    for (int p = tid; p <= n; p += nthr) { int v = A.init_tour[(size_t)b * (n + 1) + p]; t[p] = (TT)v; bt[p] = (TT)v; }
     __syncthreads();
 
     const long long t_start = wall_clock64();
@@ -409,6 +526,7 @@ __global__ void gls_kernel(GlsArgs A) {
             if (A.max_outer_iters >= 0) go = iter_i < A.max_outer_iters;
             else go = el < limit_ticks;
             if (el > watchdog_ticks) { go = 0; status = GNNGLS_STATUS_WATCHDOG_DEV; }
+            if (status != 0) go = 0;
             ctl->flag = go;
         }
         __syncthreads();
@@ -420,22 +538,49 @@ __global__ void gls_kernel(GlsArgs A) {
             int moves = 0;
             bool any_moved = false;
             long long steps = 0;
+            // utility numerators of the current tour edges, G.edges[e][guide] (algorithms.py:155), cached in
+            // registers: lane p holds positions p, p+64, ... ; reloaded (asynchronously -- the values are only
+            // consumed by the next arg-max) whenever the tour changes.
+            double gq[kGuidePasses];
+            int pq[kGuidePasses];                  // penalties of the same tour edges
+            const bool greg = n <= kGuidePasses * kWave;
+            auto reload_guides = [&]() {
+                if (!greg) return;
+#pragma unroll
+                for (int q = 0; q < kGuidePasses; ++q) {
+                    const int p = lane + q * kWave;
+                    if (p < n) { const int u = t[p], v = t[p + 1]; gq[q] = guide[(size_t)u * n + v]; pq[q] = s.pen(u, v); }
+                }
+            };
+            reload_guides();
             while (moves < A.perturbation_moves) {
                 // arg-max utility over tour edges, first maximum wins (algorithms.py:153-159)
                 double bu = 0.0; int bp = kNoKey;
-                for (int p = lane; p < n; p += kWave) {
-                    int u = t[p], v = t[p + 1];
-                    double util = guide[(size_t)u * n + v] / (1.0 + (double)s.pen(u, v));
-                    if (bp == kNoKey || util > bu) { bu = util; bp = p; }
-                }
+                if (greg) {
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    double ou = __shfl_xor(bu, o, kWave); int op_ = __shfl_xor(bp, o, kWave);
-                    bool take = (op_ != kNoKey) && (bp == kNoKey || ou > bu || (ou == bu && op_ < bp));
-                    if (take) { bu = ou; bp = op_; }
+                    for (int q = 0; q < kGuidePasses; ++q) {
+                        const int p = lane + q * kWave;
+                        if (p < n) {
+                            double util = gq[q] / (1.0 + (double)pq[q]);
+                            if (bp == kNoKey || util > bu) { bu = util; bp = p; }
+                        }
+                    }
+                } else {
+                    for (int p = lane; p < n; p += kWave) {
+                        int u = t[p], v = t[p + 1];
+                        double util = guide[(size_t)u * n + v] / (1.0 + (double)s.pen(u, v));
+                        if (bp == kNoKey || util > bu) { bu = util; bp = p; }
+                    }
                 }
+                wave_argmax_first(bu, bp);
                 const int eu = t[bp], ev = t[bp + 1];
-                if (lane == 0) s.pen_inc(eu, ev);                              // algorithms.py:161
+                bool ovf = false;
+                if (lane == 0) ovf = s.pen_inc(eu, ev);                        // algorithms.py:161
+                if (__builtin_amdgcn_readfirstlane((int)ovf)) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
+                if (greg) {
+#pragma unroll
+                    for (int q = 0; q < kGuidePasses; ++q) if (bp == lane + q * kWave) pq[q] += 1;
+                }
                 wave_sync();
                 for (int side = 0; side < 2; ++side) {                         // algorithms.py:167
                     const int node = side == 0 ? eu : ev;
@@ -455,10 +600,11 @@ __global__ void gls_kernel(GlsArgs A) {
                         if (lane == 0) evals += (op == 0) ? (n - 3) : (n - 2);
                         if (bk != kNoKey) {                                    // algorithms.py:175
                             apply_move(s, t, t2, Ef, Eb, n, op, i, bk, lane, kWave, eager_cost);
-                            int32_t *x = t; t = t2; t2 = x;
+                            TT *x = t; t = t2; t2 = x;
                             wave_sync();
                             any_moved = true;
                             moves += 1;                                        // algorithms.py:185
+                            reload_guides();
                             if (eager_cost) {
                                 cur_cost = tour_cost_from_edges(Ef, n);        // algorithms.py:176
                                 if (lane == 0) tr.push(cur_cost);
@@ -484,8 +630,8 @@ __global__ void gls_kernel(GlsArgs A) {
         }
         __syncthreads();
         {
-            int32_t *cur = reinterpret_cast<int32_t *>(smem + ctl->pad);
-            if (cur != t) { int32_t *x = t; t = t2; t2 = x; }
+            TT *cur = reinterpret_cast<TT *>(smem + ctl->pad);
+            if (cur != t) { TT *x = t; t = t2; t2 = x; }
             cur_cost = ctl->cost;
         }
 
@@ -500,7 +646,7 @@ __global__ void gls_kernel(GlsArgs A) {
     }
 
     // ---- outputs ----
-    for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = bt[p];
+    for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = (int32_t)bt[p];
     if (tid == 0) {
         A.best_cost[b] = best_cost;
         if (A.outer_iters) A.outer_iters[b] = iter_i;
@@ -604,12 +750,7 @@ __global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32
             double x = w[(size_t)cur * n + j];
             if (bj == kNoKey || x < bw) { bw = x; bj = j; }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            double ow = __shfl_xor(bw, o, kWave); int oj = __shfl_xor(bj, o, kWave);
-            bool take = (oj != kNoKey) && (bj == kNoKey || ow < bw || (ow == bw && oj < bj));
-            if (take) { bw = ow; bj = oj; }
-        }
+        { double nb = -bw; wave_argmax_first(nb, bj); }   // min weight, ties -> lowest node id
         if (lane == 0) { t[len] = bj; visited[bj] = 1; }
         wave_sync();
         cur = bj;
@@ -619,21 +760,22 @@ __global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------------------
-size_t gls_lds_bytes(int n, bool tri) {
+size_t gls_lds_bytes(int n, int store, int penalty_bits) {
     auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * 4);
-    if (!tri) off += r16((size_t)(n + 2) * 8);
-    if (tri) {
-        size_t ntri = (size_t)n * (n - 1) / 2;
-        off += r16(ntri * 8) + r16(ntri * 4);
-    }
+    const size_t tour_elem = store == GLS_STORE_COMPACT ? 1 : 4;
+    size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * tour_elem);
+    if (store == GLS_STORE_GLOBAL) off += r16((size_t)(n + 2) * 8);
+    size_t ntri = (size_t)n * (n - 1) / 2;
+    if (store != GLS_STORE_GLOBAL) off += r16(ntri * 8);
+    if (store == GLS_STORE_TRI) off += r16(ntri * (size_t)(penalty_bits / 8));
     return off;
 }
 
 int gls_block_threads(int n) {
     if (n <= 24) return 64;
     if (n <= 48) return 128;
-    return 256;
+    if (n <= 80) return 256;
+    return 512;
 }
 
 template <class S, bool FI>
@@ -647,11 +789,18 @@ static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_gls(const GlsArgs &A, bool tri, bool first_improvement, hipStream_t stream) {
-    size_t lds = gls_lds_bytes(A.n, tri);
-    int threads = gls_block_threads(A.n);
-    if (tri) return first_improvement ? launch_gls_t<TriStore, true>(A, lds, threads, stream)
-                                      : launch_gls_t<TriStore, false>(A, lds, threads, stream);
+hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
+                      hipStream_t stream) {
+    size_t lds = gls_lds_bytes(A.n, store, penalty_bits);
+    if (store == GLS_STORE_COMPACT)
+        return first_improvement ? launch_gls_t<TriDGlobalP, true>(A, lds, threads, stream)
+                                 : launch_gls_t<TriDGlobalP, false>(A, lds, threads, stream);
+    if (store == GLS_STORE_TRI && penalty_bits == 16)
+        return first_improvement ? launch_gls_t<TriStore<uint16_t>, true>(A, lds, threads, stream)
+                                 : launch_gls_t<TriStore<uint16_t>, false>(A, lds, threads, stream);
+    if (store == GLS_STORE_TRI)
+        return first_improvement ? launch_gls_t<TriStore<int32_t>, true>(A, lds, threads, stream)
+                                 : launch_gls_t<TriStore<int32_t>, false>(A, lds, threads, stream);
     return first_improvement ? launch_gls_t<GlobalStore, true>(A, lds, threads, stream)
                              : launch_gls_t<GlobalStore, false>(A, lds, threads, stream);
 }

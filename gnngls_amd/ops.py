@@ -102,13 +102,18 @@ class GlsResult:
     status: torch.Tensor         # [B] int32
 
 
+STATUS_OK, STATUS_WATCHDOG, STATUS_PENALTY_OVERFLOW = 0, 1, 2
+
+
 def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improvement=False,
             max_outer_iters=-1, time_limit_s=0.0, watchdog_s=None, trace_cap=0, want_trace_time=False,
-            want_penalty=False):
+            want_penalty=False, penalty_bits=0, retry_overflow=True):
     """guided_local_search (reference algorithms.py:135-195) for a batch of instances.
 
     D [B,n,n] fp64 symmetric, guides [G,B,n,n] fp64 (or None when max_outer_iters == 0 ->
-    local_search only), init_tour [B,n+1] int32, init_cost [B] fp64."""
+    local_search only), init_tour [B,n+1] int32, init_cost [B] fp64.
+    penalty_bits: 0 = auto (see include/gnngls_hip.h).  With retry_overflow (default) instances whose
+    16-bit penalty counters overflowed are rerun with 32-bit counters (needs a host sync)."""
     B, n = _check_shapes(init_tour, D)
     dev = D.device
     G = 0
@@ -130,12 +135,25 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
     L = _lib.load()
     _lib.check(L.gnngls_gls_run(
         _lib.ptr(D), _lib.ptr(guides), G, B, n, _lib.ptr(init_tour), _lib.ptr(init_cost),
-        int(perturbation_moves), int(first_improvement), ctypes.c_int64(int(max_outer_iters)),
+        int(perturbation_moves), int(first_improvement), int(penalty_bits), ctypes.c_int64(int(max_outer_iters)),
         float(time_limit_s), float(watchdog_s),
         _lib.ptr(best_tour), _lib.ptr(best_cost), _lib.ptr(outer),
         _lib.ptr(trace_cost), _lib.ptr(trace_time), int(trace_cap), _lib.ptr(trace_len),
         _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status), _lib.current_stream()), "gls_run")
-    return GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
+    res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
+    if retry_overflow and penalty_bits != 32:
+        bad = (status == STATUS_PENALTY_OVERFLOW).nonzero().flatten()
+        if bad.numel() > 0:
+            sub = gls_run(D[bad].contiguous(), None if guides is None else guides[:, bad].contiguous(),
+                          init_tour[bad].contiguous(), init_cost[bad].contiguous(), perturbation_moves,
+                          first_improvement, max_outer_iters, time_limit_s, watchdog_s, trace_cap, want_trace_time,
+                          want_penalty, penalty_bits=32, retry_overflow=False)
+            for name in ("best_tour", "best_cost", "outer_iters", "trace_cost", "trace_time", "trace_len", "penalty",
+                         "evals", "status"):
+                dst, src = getattr(res, name), getattr(sub, name)
+                if dst is not None:
+                    dst[bad] = src
+    return res
 
 
 def gls_resident_capacity(n):

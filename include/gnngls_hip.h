@@ -39,6 +39,7 @@ extern "C" {
 /* per-instance status words written by gnngls_gls_run */
 #define GNNGLS_STATUS_OK 0
 #define GNNGLS_STATUS_WATCHDOG 1      /* watchdog fired (search aborted, best-so-far returned) */
+#define GNNGLS_STATUS_PENALTY_OVERFLOW 2   /* a 16-bit LDS penalty counter would pass 65535: rerun with penalty_bits=32 */
 
 int gnngls_abi_version(void);
 const char *gnngls_last_error(void);
@@ -84,6 +85,10 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  *                          0 = local_search only (algorithms.py:142)
  *   max_outer_iters <  0 : run until time_limit_s seconds of device wall clock have elapsed since
  *                          the workgroup started (reference mode, `while time.time() < t_lim`)
+ *   penalty_bits width of the LDS-resident penalty counters (algorithms.py:138,161): 32, 16, or
+ *                0 = auto (16 only where it buys one more resident workgroup per CU, e.g. n=100:
+ *                3 instead of 2).  A 16-bit counter about to overflow stops that instance with
+ *                GNNGLS_STATUS_PENALTY_OVERFLOW; the caller reruns it with penalty_bits=32.
  *   watchdog_s   hard abort (status GNNGLS_STATUS_WATCHDOG) if a workgroup runs longer than this
  *   outputs      best_tour [B,n+1], best_cost [B], outer_iters [B] (int64),
  *                trace_cost [B,trace_cap] cost after every accepted move (algorithms.py:127-130,
@@ -95,7 +100,7 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  * end of each perturbation phase -- the values that drive decisions are unchanged. */
 int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, int n,
                    const int32_t *init_tour, const double *init_cost,
-                   int perturbation_moves, int first_improvement,
+                   int perturbation_moves, int first_improvement, int penalty_bits,
                    int64_t max_outer_iters, double time_limit_s, double watchdog_s,
                    int32_t *best_tour, double *best_cost, int64_t *outer_iters,
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
@@ -135,6 +140,10 @@ int gnngls_pack_features(const double *D, int B, int n, double scale, double min
 /* test.py:79-83: regret_pred = max(MinMaxScaler.inverse_transform(y_pred), 0) as a symmetric fp64
  * [B,n,n] matrix (zero diagonal) -- the 'regret_pred' guide of guided_local_search. */
 int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream);
+
+/* Test hook: lowers the value at which a 16-bit penalty counter reports overflow (default 65535) so
+ * the overflow -> rerun-with-32-bit path can be exercised in seconds.  Never called by the product. */
+int gnngls_debug_set_penalty16_limit(int limit);
 
 /* ---- measurement hooks (bench.py): per-kernel-class device time via HIP events recorded on the
  * caller's stream around every launch made while profiling is enabled.  gnngls_profile_collect

@@ -38,6 +38,7 @@ def test_host_queries(lib):
     caps = [lib.gnngls_gls_resident_capacity(n) for n in (20, 50, 100, 150)]
     assert all(c > 0 for c in caps) and caps == sorted(caps, reverse=True)
     assert lib.gnngls_gls_resident_capacity(400) == 0            # triangles exceed 160 KiB of LDS
+    assert lib.gnngls_gls_resident_capacity(100) == 4 * 256       # compact store: 4 workgroups per CU
     n_layers = 8
     per_layer = 128 * 128 + 4 * 128 + 512 * 128 + 512 + 128 * 512 + 3 * 128
     assert lib.gnngls_model_packed_floats(1, n_layers) == 128 + 128 + n_layers * per_layer + 128 + 4
@@ -49,7 +50,7 @@ def test_bad_arguments_are_rejected(lib):
     assert lib.gnngls_tour_cost(None, None, 1, 5, None, None) == -1
     assert b"tour_cost" in lib.gnngls_last_error()
     with pytest.raises(_lib.GnnglsHipError):
-        _lib.check(lib.gnngls_gls_run(None, None, 0, 1, 5, None, None, 20, 0, 0, 0.0, 1.0, None, None, None, None, None,
+        _lib.check(lib.gnngls_gls_run(None, None, 0, 1, 5, None, None, 20, 0, 0, 0, 0.0, 1.0, None, None, None, None, None,
                                       0, None, None, None, None, None), "gls_run")
 
 

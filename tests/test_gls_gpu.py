@@ -194,3 +194,40 @@ def test_gls_time_mode_and_properties(ops):
         La = int(a.trace_len[b])
         assert int(b2.trace_len[b]) >= La
         assert torch.equal(a.trace_cost[b, :La], b2.trace_cost[b, :La])
+
+
+@pytest.mark.parametrize("bits", [0, 16, 32])
+def test_gls_penalty_width_variants(ops, bits):
+    """Both LDS penalty widths give the reference's results (golden, TSP100)."""
+    g = np.load(os.path.join(GOLD, "gls_c7_n100_K20.npz"))
+    r = ops.gls_run(dev(g["D"][None], torch.float64), dev(g["guides"][:, None], torch.float64),
+                    dev(g["init_tour"][None], torch.int32), dev(np.array([g["init_cost"]]), torch.float64),
+                    perturbation_moves=int(g["perturbation_moves"]), max_outer_iters=int(g["K"]), trace_cap=8192,
+                    want_penalty=True, penalty_bits=bits)
+    assert int(r.status[0]) == 0
+    assert_bits(r.trace_cost[0, :len(g["trace"])].cpu().numpy(), g["trace"])
+    assert r.best_tour[0].cpu().tolist() == g["best_tour"].tolist()
+    assert np.array_equal(r.penalty[0].cpu().numpy(), g["penalty"])
+
+
+def test_gls_penalty16_overflow_is_detected_and_rerun(ops):
+    """A 16-bit penalty counter that would overflow stops the instance with status 2; ops.gls_run reruns
+    it with 32-bit counters, so the final result equals the 32-bit run (test hook lowers the limit)."""
+    from gnngls_amd import _lib
+    g = np.load(os.path.join(GOLD, "gls_c7_n100_K20.npz"))
+    assert g["penalty"].max() > 2
+    args = (dev(g["D"][None], torch.float64), dev(g["guides"][:, None], torch.float64),
+            dev(g["init_tour"][None], torch.int32), dev(np.array([g["init_cost"]]), torch.float64))
+    kw = dict(perturbation_moves=int(g["perturbation_moves"]), max_outer_iters=int(g["K"]), trace_cap=8192, want_penalty=True)
+    L = _lib.load()
+    _lib.check(L.gnngls_debug_set_penalty16_limit(2))
+    try:
+        raw = ops.gls_run(*args, penalty_bits=16, retry_overflow=False, **kw)
+        assert int(raw.status[0]) == ops.STATUS_PENALTY_OVERFLOW
+        r = ops.gls_run(*args, penalty_bits=16, **kw)
+    finally:
+        _lib.check(L.gnngls_debug_set_penalty16_limit(65535))
+    assert int(r.status[0]) == 0
+    assert_bits(r.trace_cost[0, :len(g["trace"])].cpu().numpy(), g["trace"])
+    assert r.best_tour[0].cpu().tolist() == g["best_tour"].tolist()
+    assert np.array_equal(r.penalty[0].cpu().numpy(), g["penalty"])
