@@ -19,6 +19,7 @@
 //       gat_combine_kernel: log-sum-exp merge of the two row partials of a destination + skip + BN1
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "model_kernels.h"
 
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 //   written to side (i<j ? 0 : 1) of the partial buffers; the other endpoint's row supplies the
 //   second half of the 2(n-2) in-neighbours.
 // ---------------------------------------------------------------------------------------------
+constexpr int LDF = kD + 16;   // LDS row stride of the staged ft tile (floats): the 4 source rows an MFMA
+                               // B-fragment read touches land on 4 disjoint groups of 16 banks
+
 __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__ ft, const float *__restrict__ attn_l,
                                                        const float *__restrict__ attn_r, int n,
                                                        float *__restrict__ part, float *__restrict__ part_ms) {
@@ -215,11 +219,11 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
     const int N = n * (n - 1) / 2;
     const int ns = n - 1;
     const int b = blockIdx.x / n, i = blockIdx.x % n;
-    const int tid = threadIdx.x;
-    float *ftS = reinterpret_cast<float *>(smem);            // [ns][128]
-    float *elS = ftS + (size_t)ns * kD;                      // [ns][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *ftS = reinterpret_cast<float *>(smem);            // [ns][LDF]
+    float *elS = ftS + (size_t)ns * LDF;                     // [ns][8]
     float *erS = elS + (size_t)ns * kH;                      // [ns][8]
-    float *top = erS + (size_t)ns * kH;                      // [8][4]: max1, max2, argmax1(as float bits), unused
+    float *top = erS + (size_t)ns * kH;                      // [8][4]: max1, max2, argmax1 (int bits), unused
     int *nodeS = reinterpret_cast<int *>(top + kH * 4);      // [ns] global node id of slot
 
     const float *ftb = ft + (size_t)b * N * kD;
@@ -228,73 +232,118 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
         nodeS[s] = k < i ? pair_index(k, i, n) : pair_index(i, k, n);
     }
     __syncthreads();
-    // stage ft rows: 32 float4 per node
-    for (int q = tid; q < ns * (kD / 4); q += 256) {
+    for (int q = tid; q < ns * (kD / 4); q += 256) {         // stage ft rows: 32 x 16 B per node, coalesced
         int s = q >> 5, c = (q & 31) * 4;
-        *reinterpret_cast<f32x4 *>(ftS + (size_t)s * kD + c) =
+        *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDF + c) =
             *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[s] * kD + c);
     }
     __syncthreads();
-    // el / er (GATConv: (feat * attn).sum(-1))
-    for (int q = tid; q < ns * kH; q += 256) {
+    for (int q = tid; q < ns * kH; q += 256) {               // el / er (GATConv: (feat * attn).sum(-1))
         int s = q >> 3, h = q & 7;
-        const float *f = ftS + (size_t)s * kD + h * kF;
+        const float *f = ftS + (size_t)s * LDF + h * kF;
         float l = 0.f, r = 0.f;
 #pragma unroll
         for (int u = 0; u < kF; ++u) { l = fmaf(f[u], attn_l[h * kF + u], l); r = fmaf(f[u], attn_r[h * kF + u], r); }
         elS[q] = l; erS[q] = r;
     }
     __syncthreads();
-    if (tid < kH) {      // top-2 of el per head over the row's sources
+    {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles
+        const int h = tid >> 5, l32 = tid & 31;
         float m1 = -INFINITY, m2 = -INFINITY; int a1 = -1;
-        for (int s = 0; s < ns; ++s) {
-            float v = elS[s * kH + tid];
+        for (int s = l32; s < ns; s += 32) {
+            float v = elS[s * kH + h];
             if (v > m1) { m2 = m1; m1 = v; a1 = s; } else if (v > m2) { m2 = v; }
         }
-        top[tid * 4 + 0] = m1; top[tid * 4 + 1] = m2; top[tid * 4 + 2] = __int_as_float(a1);
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            float om1 = __shfl_xor(m1, o, 32), om2 = __shfl_xor(m2, o, 32);
+            int oa1 = __shfl_xor(a1, o, 32);
+            // merge two (max1, arg1, max2) triples; on equal maxima keep the lower source index
+            bool take = om1 > m1 || (om1 == m1 && oa1 >= 0 && (a1 < 0 || oa1 < a1));
+            float lo1 = take ? m1 : om1;                 // the loser's best is a candidate for second place
+            float hi2 = take ? om2 : m2;
+            if (take) { m1 = om1; a1 = oa1; }
+            m2 = lo1 > hi2 ? lo1 : hi2;
+        }
+        if (l32 == 0) { top[h * 4 + 0] = m1; top[h * 4 + 1] = m2; top[h * 4 + 2] = __int_as_float(a1); }
     }
     __syncthreads();
 
-    const int JS = (ns + 63) & ~63;            // destination slots padded to whole waves
+    // ---- weighted aggregation on v_mfma_f32_16x16x4_f32 -------------------------------------------
+    // one unit = (tile of 16 destinations, pair of heads); D[16 dest x 16 feat] += A[16 dest x 4 src] * B[4 src x 16 feat]
+    //   A[i = lane&15][k = lane>>4] = exp(LeakyReLU(el[src] + er[dest]) - m[dest])   (computed in the lane)
+    //   B[k = lane>>4][j = lane&15] = ft[src][head*16 + j]                            (LDS tile)
+    const float kLog2e = 1.4426950408889634f;
+    const int n_dt = (ns + 15) >> 4;
+    const int jl = lane & 15, kq = lane >> 4;
     float *pb = part + (size_t)b * N * kD;
     float *mb = part_ms + (size_t)b * N * (2 * kH);
     const size_t side_stride = (size_t)gridDim.x / n * N;     // B*N nodes per side
-    for (int item = tid; item < JS * kH; item += 256) {
-        const int js = item % JS, h = item / JS;
-        if (js >= ns) continue;
-        const float er = erS[js * kH + h];
-        float mrow = (__float_as_int(top[h * 4 + 2]) == js) ? top[h * 4 + 1] : top[h * 4 + 0];
-        float mm = mrow + er;
-        mm = mm > 0.f ? mm : kSlope * mm;      // LeakyReLU is monotone: max of scores = score of max el
-        float acc[kF];
+    constexpr int HU = 4;                                      // heads per unit (independent MFMA chains)
+    for (int unit = wave; unit < n_dt * (kH / HU); unit += 4) {
+        const int dt = unit / (kH / HU), h0 = (unit % (kH / HU)) * HU;
+        const int js = dt * 16 + jl;
+        const int jsc = js < ns ? js : ns - 1;
+        float er[HU], mm[HU], nm[HU], ws[HU];
+        f32x4 acc[HU];
 #pragma unroll
-        for (int u = 0; u < kF; ++u) acc[u] = 0.f;
-        float ssum = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            float sc = elS[s * kH + h] + er;
-            sc = sc > 0.f ? sc : kSlope * sc;
-            float w = __expf(sc - mm);
-            w = (s == js) ? 0.f : w;           // no self loop: source {i,j} is not a neighbour of itself
-            ssum += w;
-            const f32x4 *f = reinterpret_cast<const f32x4 *>(ftS + (size_t)s * kD + h * kF);
+        for (int u = 0; u < HU; ++u) {
+            const int h = h0 + u;
+            er[u] = erS[jsc * kH + h];
+            float m = ((__float_as_int(top[h * 4 + 2]) == js) ? top[h * 4 + 1] : top[h * 4 + 0]) + er[u];
+            mm[u] = m > 0.f ? m : kSlope * m;      // LeakyReLU is monotone: max score = score of max el
+            nm[u] = -mm[u] * kLog2e;
+            ws[u] = 0.f;
+            acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // two source groups (2 x 4 sources) per iteration: 8 independent exp + 8 MFMAs in flight
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            int sidx[2]; bool live[2];
+            f32x4 e[2];
+            float bv[2][HU];
 #pragma unroll
-            for (int v4 = 0; v4 < 4; ++v4) {
-                f32x4 x = f[v4];
-                acc[4 * v4 + 0] = fmaf(w, x[0], acc[4 * v4 + 0]);
-                acc[4 * v4 + 1] = fmaf(w, x[1], acc[4 * v4 + 1]);
-                acc[4 * v4 + 2] = fmaf(w, x[2], acc[4 * v4 + 2]);
-                acc[4 * v4 + 3] = fmaf(w, x[3], acc[4 * v4 + 3]);
+            for (int g = 0; g < 2; ++g) {
+                const int s = s0 + 4 * g + kq;
+                sidx[g] = s < ns ? s : ns - 1;
+                live[g] = (s < ns) && (s != js);              // no self loop, no padding
+                e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
+#pragma unroll
+                for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int u = 0; u < HU; ++u) {
+                    float x = e[g][u] + er[u];
+                    x = fmaxf(x, kSlope * x);                                  // LeakyReLU(x) = max(x, 0.2x)
+                    float w = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, nm[u]));
+                    w = live[g] ? w : 0.f;
+                    ws[u] += w;
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[g][u], acc[u], 0, 0, 0);
+                }
             }
         }
-        const int j = js < i ? js : js + 1;
-        const int side = i < j ? 0 : 1;
-        const size_t node = (size_t)nodeS[js];
-        float *po = pb + side * side_stride * kD + node * kD + h * kF;
+        // softmax denominators: sum the 4 source lanes (lane>>4) of every destination
 #pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4)
-            *reinterpret_cast<f32x4 *>(po + 4 * v4) = f32x4{acc[4 * v4], acc[4 * v4 + 1], acc[4 * v4 + 2], acc[4 * v4 + 3]};
-        float *mo = mb + side * side_stride * (2 * kH) + node * (2 * kH);
-        mo[h] = mm; mo[kH + h] = ssum;
+        for (int u = 0; u < HU; ++u) { ws[u] += __shfl_xor(ws[u], 16, 64); ws[u] += __shfl_xor(ws[u], 32, 64); }
+        // C/D layout 16x16: col = lane&15 (feature), row = (lane>>4)*4 + reg (destination in the tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jd = dt * 16 + kq * 4 + r;
+            if (jd < ns) {
+                const int j = jd < i ? jd : jd + 1;
+                const size_t node = (size_t)nodeS[jd];
+                float *po = pb + (i < j ? 0 : side_stride * kD) + node * kD;
+#pragma unroll
+                for (int u = 0; u < HU; ++u) po[(h0 + u) * kF + jl] = acc[u][r];
+            }
+        }
+        if (kq == 0 && js < ns) {
+            const int j = js < i ? js : js + 1;
+            float *mo = mb + (i < j ? 0 : side_stride * (2 * kH)) + (size_t)nodeS[js] * (2 * kH);
+#pragma unroll
+            for (int u = 0; u < HU; ++u) { mo[h0 + u] = mm[u]; mo[kH + h0 + u] = ws[u]; }
+        }
     }
 }
 
@@ -354,7 +403,7 @@ static int grid_for(long total, int block, int cap = 256 * 16) {
 
 size_t gat_rows_lds_bytes(int n) {
     size_t ns = (size_t)n - 1;
-    return ns * kD * 4 + 2 * ns * kH * 4 + kH * 4 * 4 + ns * 4 + 16;
+    return ns * LDF * 4 + 2 * ns * kH * 4 + kH * 4 * 4 + ns * 4 + 16;
 }
 
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st) {
