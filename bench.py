@@ -69,17 +69,16 @@ def kernel_rooflines(prof, n, B_chunk, n_layers):
                      "frac": achieved / unit_peak, "traffic": None, "avg_launch_ms": avg_s * 1e3,
                      "launches": int(launches), "total_ms": ms}
 
-    add("gemm_ffn1", ["gemm_ffn1"], "mfma", 2.0 * M * 128 * 512, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
-    add("gemm_ffn2", ["gemm_ffn2"], "mfma", 2.0 * M * 512 * 128, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
+    add("ffn_fused", ["ffn_fused"], "mfma", 4.0 * M * 128 * 512, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
     add("gemm_fc", ["gemm_fc"], "mfma", 2.0 * M * 128 * 128, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
-    # K1 (attention + aggregation + skip + BN1 = gat_rows + gat_combine), SURVEY 8(d): N*1600 B and E*304 FLOP per
+    # K1 (attention + aggregation = gat_rows; the merge + skip + BN1 is fused into ffn_fused), SURVEY 8(d): N*1600 B and E*304 FLOP per
     # (instance, layer).  Arithmetic intensity = 0.19*deg FLOP/B: above the fp32 ridge (157.3 TF / 8 TB/s = 19.7
     # FLOP/B, i.e. n > ~54) the weighted sums on the f32 MFMA are the floor, below it HBM is.
     k1_bytes, k1_flops = 1600.0 * M, 304.0 * E * B_chunk
     if k1_flops / (PEAK_MFMA_F32_TFLOPS * 1e12) > k1_bytes / (PEAK_HBM_GBS * 1e9):
-        add("gat_aggregate", ["gat_rows", "gat_combine"], "mfma", k1_flops, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
+        add("gat_aggregate", ["gat_rows"], "mfma", k1_flops, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
     else:
-        add("gat_aggregate", ["gat_rows", "gat_combine"], "hbm", k1_bytes, PEAK_HBM_GBS, "GB/s")
+        add("gat_aggregate", ["gat_rows"], "hbm", k1_bytes, PEAK_HBM_GBS, "GB/s")
     if "gat_aggregate" in out:
         t = out["gat_aggregate"]["avg_launch_ms"] * 1e-3
         out["gat_aggregate"]["algorithmic_gbs"] = k1_bytes / t / 1e9

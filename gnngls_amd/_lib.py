@@ -36,7 +36,7 @@ SIGNATURES = {
 }
 
 PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine", "gemm_ffn1", "gemm_ffn2",
-              "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls"]
+              "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls", "ffn_fused"]
 
 
 def profile_enable(on=True):

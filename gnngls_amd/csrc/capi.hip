@@ -190,7 +190,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
 // ---------------------------------------------------------------------------------------------
 namespace {
 constexpr long kLayerFloats = 128L * 128 + 128 + 128 + 128 + 128 + 512L * 128 + 512 + 128L * 512 + 128 + 128 + 128;
-constexpr long kBytesPerNode = (128 + 128 + 256 + 32 + 128 + 512) * 4L;   // h, ft, part, part_ms, h1, hid
+constexpr long kBytesPerNode = (128 + 128 + 256 + 32 + 128) * 4L;   // h, ft, part, part_ms, h2 (ping-pong)
 }  // namespace
 
 extern "C" {
@@ -226,8 +226,7 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     float *ft = h + Mc * 128;
     float *part = ft + Mc * 128;
     float *part_ms = part + 2 * Mc * 128;
-    float *h1 = part_ms + 2 * Mc * 16;
-    float *hid = h1 + Mc * 128;
+    float *h2 = part_ms + 2 * Mc * 16;
     const float *emb_w = weights, *emb_b = weights + 128L * in_dim;
     const float *layers = emb_b + 128;
     const float *dec_w = layers + (long)n_layers * kLayerFloats, *dec_b = dec_w + 128;
@@ -248,12 +247,10 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
-            { ProfScope ps(GNNGLS_PROF_GAT_COMBINE, st);
-              GNNGLS_TRY(gnngls::launch_gat_combine(part, part_ms, h, bn1_s, bn1_b, h1, M, st)); }
-            { ProfScope ps(GNNGLS_PROF_GEMM_FFN1, st);
-              GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, h1, w1, hid, M, 512, 128, b1, nullptr, nullptr, nullptr, st)); }
-            { ProfScope ps(GNNGLS_PROF_GEMM_FFN2, st);
-              GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_SKIP_BN, hid, w2, h, M, 128, 512, b2, h1, bn2_s, bn2_b, st)); }
+            // gat_combine + FFN1 + FFN2 in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
+            { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
+              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, st)); }
+            { float *x = h; h = h2; h2 = x; }
         }
         { ProfScope ps(GNNGLS_PROF_DECISION, st);
           GNNGLS_TRY(gnngls::launch_decision(h, dec_w, dec_b, y_out + b0 * N, M, st)); }               // models.py:69

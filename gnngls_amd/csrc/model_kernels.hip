@@ -375,6 +375,179 @@ __global__ void gat_combine_kernel(const float *__restrict__ part, const float *
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused feed-forward block (models.py:26-36,40), one launch per layer:
+//     x  = BN1(h + GATConv(h))          <- log-sum-exp merge of the two attention partials, fused into the
+//                                          staging of the 128-row x tile (never written to HBM)
+//     y  = BN2(x + W2 * ReLU(W1 * x + b1) + b2)
+// One workgroup = 128 rows, 4 waves, wave w owns rows [32w, 32w+32).  The 512-wide hidden layer is
+// processed in 4 chunks of 128 and never leaves the registers: GEMM1 is computed TRANSPOSED,
+//     Hc^T[hid x rows] = W1c[hid x K] * x^T[K x rows]      (A = W1 tile from LDS, B = x tile from LDS)
+// so that in the accumulator the data row sits on the lane and the hidden index in the register; those
+// registers are then fed directly as the B operand of
+//     Y^T[out x rows] += W2c[out x hid] * Hc^T[hid x rows] (A = W2 tile from LDS, B = accumulator registers)
+// with the k order of W2 permuted to the accumulator's row map (k pair of one MFMA = {hmap(r,0), hmap(r,1)}).
+// Weight tiles (128 x 32 fp32 = 16 KB) stream L2 -> registers -> LDS through a 2-deep ring, one barrier per
+// tile, 64 MFMAs (4096 cycles) per wave between barriers.  LDS: x tile 66 KB + 2 weight buffers 33.8 KB.
+// ---------------------------------------------------------------------------------------------
+constexpr int FT_M = 128;            // rows per workgroup
+constexpr int LDX = 129;             // x tile row stride (floats): "32 rows at fixed k" reads are conflict-free
+constexpr int LDW = 33;              // weight tile row stride
+
+__device__ __forceinline__ int hmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int SUB>
+__device__ __forceinline__ void ffn_gemm1_stage(f32x16 (&accH)[4], const float *Xs, const float *Wt, int wrow, int lr, int lk) {
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+        const float b = Xs[(wrow + lr) * LDX + SUB * 32 + kk + lk];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const float a = Wt[(ht * 32 + lr) * LDW + kk + lk];
+            accH[ht] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accH[ht], 0, 0, 0);
+        }
+    }
+}
+
+template <int SUB>
+__device__ __forceinline__ void ffn_gemm2_stage(f32x16 (&accY)[4], const f32x16 (&accH)[4], const float *Wt, int lr, int lk) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float b = accH[SUB][r];
+        const int hm = hmap(r, lk);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const float a = Wt[(ot * 32 + lr) * LDW + hm];
+            accY[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accY[ot], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ffn_fused_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
+                                                        const float *__restrict__ hin,
+                                                        const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
+                                                        const float *__restrict__ W1, const float *__restrict__ b1,
+                                                        const float *__restrict__ W2, const float *__restrict__ b2,
+                                                        const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
+                                                        float *__restrict__ hout, long M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *Xs = reinterpret_cast<float *>(smem_raw);        // [128][LDX]
+    float *Wb0 = Xs + FT_M * LDX;                           // [128][LDW]
+    float *Wb1 = Wb0 + 128 * LDW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int wrow = wave * 32;
+    const long row0 = (long)blockIdx.x * FT_M;
+
+    // ---- stage the x tile: x = BN1(h + merge(partials))  (gat_combine fused; models.py:15,24,28) ----
+    for (int it = 0; it < (FT_M * 32) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
+        const long m = row0 + row;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (m < M) {
+            const float *ms0 = part_ms + m * (2 * kH), *ms1 = part_ms + (M + m) * (2 * kH);
+            const float m0 = ms0[hd], s0 = ms0[kH + hd], m1 = ms1[hd], s1 = ms1[kH + hd];
+            const float mx = m0 > m1 ? m0 : m1;
+            const float a0 = __expf(m0 - mx), a1 = __expf(m1 - mx);
+            const float inv = 1.f / (s0 * a0 + s1 * a1);
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(part + m * kD + c);
+            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(part + (M + m) * kD + c);
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(hin + m * kD + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float g = (p0[u] * a0 + p1[u] * a1) * inv;
+                o[u] = (hv[u] + g) * bn1_s[c + u] + bn1_b[c + u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Xs[row * LDX + c + u] = o[u];
+    }
+
+    // ---- weight tile stream: tile t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1, 1: W2), sub = t&3 ----
+    const int srow = tid >> 1, sk = (tid & 1) * 16;
+    f32x4 rw[4];
+    auto gload = [&](int t) {
+        const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
+        const float *src = ph == 0 ? W1 + (long)(c * 128 + srow) * 128 + sub * 32 + sk       // W1[hid][k]
+                                   : W2 + (long)srow * 512 + c * 128 + sub * 32 + sk;        // W2[out][hid]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rw[u] = *reinterpret_cast<const f32x4 *>(src + 4 * u);
+    };
+    auto lstore = [&](float *Wt) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Wt[srow * LDW + sk + 4 * u + c] = rw[u][c];
+    };
+    gload(0);
+    lstore(Wb0);
+    __syncthreads();
+
+    f32x16 accY[4], accH[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accY[a][r] = 0.f;
+
+#define FFN_STAGE(S, BODY)                                                                  \
+    {                                                                                       \
+        const int t = c * 8 + (S);                                                          \
+        if (t + 1 < 32) gload(t + 1);                                                       \
+        const float *Wt = ((S) & 1) ? Wb1 : Wb0;                                            \
+        BODY;                                                                               \
+        if (t + 1 < 32) lstore(((S) & 1) ? Wb0 : Wb1);                                      \
+        __syncthreads();                                                                    \
+    }
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        // hidden pre-activations start at the bias (C-in of the MFMA chain), models.py:30
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accH[ht][r] = b1[c * 128 + ht * 32 + hmap(r, lk)];
+        FFN_STAGE(0, (ffn_gemm1_stage<0>(accH, Xs, Wt, wrow, lr, lk)))
+        FFN_STAGE(1, (ffn_gemm1_stage<1>(accH, Xs, Wt, wrow, lr, lk)))
+        FFN_STAGE(2, (ffn_gemm1_stage<2>(accH, Xs, Wt, wrow, lr, lk)))
+        FFN_STAGE(3, (ffn_gemm1_stage<3>(accH, Xs, Wt, wrow, lr, lk)))
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accH[ht][r] = accH[ht][r] > 0.f ? accH[ht][r] : 0.f;   // ReLU, models.py:31
+        FFN_STAGE(4, (ffn_gemm2_stage<0>(accY, accH, Wt, lr, lk)))
+        FFN_STAGE(5, (ffn_gemm2_stage<1>(accY, accH, Wt, lr, lk)))
+        FFN_STAGE(6, (ffn_gemm2_stage<2>(accY, accH, Wt, lr, lk)))
+        FFN_STAGE(7, (ffn_gemm2_stage<3>(accY, accH, Wt, lr, lk)))
+    }
+#undef FFN_STAGE
+
+    // ---- epilogue: y = BN2(x + (acc + b2)); transposed accumulator -> x tile in LDS -> coalesced rows ----
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int out = ot * 32 + hmap(r, lk);
+            float *xp = Xs + (wrow + lr) * LDX + out;
+            float v = accY[ot][r] + b2[out];          // Linear2 output (models.py:32)
+            v = *xp + v;                              // x + y            (models.py:15)
+            *xp = v * bn2_s[out] + bn2_b[out];        // BatchNorm1d eval (models.py:35)
+        }
+    }
+    __syncthreads();
+    for (int it = 0; it < (FT_M * 32) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 5, c = (idx & 31) * 4;
+        const long m = row0 + row;
+        if (m < M) {
+            f32x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = Xs[row * LDX + c + u];
+            *reinterpret_cast<f32x4 *>(hout + m * kD + c) = o;
+        }
+    }
+}
+
 // decision layer (models.py:63,69) for out_dim = 1: y[m] = h[m,:] . w + b ; 32 lanes per row
 __global__ void decision_kernel(const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
                                 float *__restrict__ y, long M) {
@@ -455,6 +628,19 @@ hipError_t launch_gat_combine(const float *part, const float *part_ms, const flo
                               const float *bn_shift, float *out, long M, hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(gat_combine_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, part, part_ms, h, bn_scale, bn_shift, out, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
+                            const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
+    const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, part, part_ms, hin,
+                       bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M);
     return hipGetLastError();
 }
 

@@ -152,7 +152,7 @@ int gnngls_debug_set_penalty16_limit(int limit);
 enum {
     GNNGLS_PROF_PACK = 0, GNNGLS_PROF_EMBED, GNNGLS_PROF_GEMM_FC, GNNGLS_PROF_GAT_ROWS, GNNGLS_PROF_GAT_COMBINE,
     GNNGLS_PROF_GEMM_FFN1, GNNGLS_PROF_GEMM_FFN2, GNNGLS_PROF_DECISION, GNNGLS_PROF_UNPACK,
-    GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_KINDS
+    GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_FFN_FUSED, GNNGLS_PROF_KINDS
 };
 int gnngls_profile_enable(int on);
 int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);

@@ -42,7 +42,7 @@ def test_host_queries(lib):
     n_layers = 8
     per_layer = 128 * 128 + 4 * 128 + 512 * 128 + 512 + 128 * 512 + 3 * 128
     assert lib.gnngls_model_packed_floats(1, n_layers) == 128 + 128 + n_layers * per_layer + 128 + 4
-    assert lib.gnngls_regret_forward_workspace_bytes(2, 100) > 2 * 4950 * 128 * 4 * 9
+    assert lib.gnngls_regret_forward_workspace_bytes(2, 100) > 2 * 4950 * 128 * 4 * 5
 
 
 def test_bad_arguments_are_rejected(lib):
