@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", SO]
+    cmd = [hipcc] + FLAGS + os.environ.get("GNNGLS_EXTRA_FLAGS", "").split() + sources() + ["-o", SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

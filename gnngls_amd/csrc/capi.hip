@@ -64,13 +64,16 @@ int num_cus() {
 struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; };
 
 GlsConfig gls_config(int n, int requested_bits) {
-    const int threads = gnngls::gls_block_threads(n);
-    const int by_waves = kMaxWavesPerCU / (threads / 64);
-    GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, threads, gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0};
+    GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, gnngls::gls_block_threads(n, gnngls::GLS_STORE_GLOBAL),
+                   gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0};
     bool have = false;
     auto consider = [&](int store, int bits) {
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
+        const int threads = gnngls::gls_block_threads(n, store);
+        // wave slots per CU at the kernel's register budget: 80 VGPRs -> 6 waves per SIMD (24 per CU);
+        // the compact-store variant is compiled for 64 VGPRs -> 8 per SIMD (32 per CU)
+        const int by_waves = (store == gnngls::GLS_STORE_COMPACT ? 32 : 24) / (threads / 64);
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;
         if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }

@@ -33,7 +33,7 @@ struct GlsArgs {
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
 size_t gls_lds_bytes(int n, int store, int penalty_bits);
-int gls_block_threads(int n);
+int gls_block_threads(int n, int store);
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
                       hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);

@@ -36,7 +36,21 @@ namespace gnngls {
 
 constexpr int kWave = 64;
 constexpr int kNoKey = INT_MAX;
-constexpr int kGuidePasses = 4;   // register-cached guide values cover n <= 256
+constexpr int kGuidePassesMax = 4;   // register-cached guide values cover n <= 256
+
+// Diagnostic build only (-DGLS_STAMPS): per-phase shader-cycle totals of the search kernel, written to
+// a side buffer that nothing else reads.  The shipped library is built without it.
+#ifdef GLS_STAMPS
+#define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = 0
+#define STAMP_BEGIN() st_t = clock64()
+#define STAMP_END(i) do { long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; } while (0)
+#define STAMP_COUNT(i) st_acc[i] += 1
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN()
+#define STAMP_END(i)
+#define STAMP_COUNT(i)
+#endif   // register-cached guide values cover n <= 256
 
 __device__ __forceinline__ int make_key(int i, int j) { return (i << 16) | j; }
 
@@ -92,7 +106,7 @@ struct TriDGlobalP {
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
-    static constexpr int kWavesPerSimd = 8;      // 4 workgroups of 8 waves per CU
+    static constexpr int kWavesPerSimd = 8;      // 4 workgroups of 8 waves per CU (64 VGPRs)
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
         return ((hi * (hi - 1)) >> 1) + lo;
@@ -355,6 +369,7 @@ __device__ __forceinline__ void scan_relocate_a2a(const S &s, const TT *t, const
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
                                                  int tid, int nthr, double &bd, int &bk) {
+#pragma unroll 2
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         int dj = i - j; if (dj < 0) dj = -dj;
         if (dj < 2) continue;                                // operators.py:61-62
@@ -364,6 +379,7 @@ __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n,
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n, int i,
                                                   int tid, int nthr, double &bd, int &bk) {
+#pragma unroll 2
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         if (j == i) continue;                                // operators.py:114-115
         consider<FI>(relocate_cost(t, f, i, j), j, bd, bk);
@@ -447,7 +463,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 
 // launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
 // CU at n=100 need <= 80 VGPRs), 4 for the global-memory fallback.
-template <class S, bool FI>
+template <class S, bool FI, int GP>
 __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -507,6 +523,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     long long evals = 0;
     int phase = 0;
     int status = 0;
+    STAMP_DECL;
 
     local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
@@ -535,19 +552,20 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
 
         // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
         if (wave == 0) {
+            STAMP_BEGIN();
             int moves = 0;
             bool any_moved = false;
             long long steps = 0;
             // utility numerators of the current tour edges, G.edges[e][guide] (algorithms.py:155), cached in
             // registers: lane p holds positions p, p+64, ... ; reloaded (asynchronously -- the values are only
             // consumed by the next arg-max) whenever the tour changes.
-            double gq[kGuidePasses];
-            int pq[kGuidePasses];                  // penalties of the same tour edges
-            const bool greg = n <= kGuidePasses * kWave;
+            double gq[GP];
+            int pq[GP];                  // penalties of the same tour edges
+            const bool greg = n <= GP * kWave;
             auto reload_guides = [&]() {
                 if (!greg) return;
 #pragma unroll
-                for (int q = 0; q < kGuidePasses; ++q) {
+                for (int q = 0; q < GP; ++q) {
                     const int p = lane + q * kWave;
                     if (p < n) { const int u = t[p], v = t[p + 1]; gq[q] = guide[(size_t)u * n + v]; pq[q] = s.pen(u, v); }
                 }
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                 double bu = 0.0; int bp = kNoKey;
                 if (greg) {
 #pragma unroll
-                    for (int q = 0; q < kGuidePasses; ++q) {
+                    for (int q = 0; q < GP; ++q) {
                         const int p = lane + q * kWave;
                         if (p < n) {
                             double util = gq[q] / (1.0 + (double)pq[q]);
@@ -573,13 +591,14 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                     }
                 }
                 wave_argmax_first(bu, bp);
+                STAMP_END(0);   // utility arg-max
                 const int eu = t[bp], ev = t[bp + 1];
                 bool ovf = false;
                 if (lane == 0) ovf = s.pen_inc(eu, ev);                        // algorithms.py:161
                 if (__builtin_amdgcn_readfirstlane((int)ovf)) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
                 if (greg) {
 #pragma unroll
-                    for (int q = 0; q < kGuidePasses; ++q) if (bp == lane + q * kWave) pq[q] += 1;
+                    for (int q = 0; q < GP; ++q) if (bp == lane + q * kWave) pq[q] += 1;
                 }
                 wave_sync();
                 for (int side = 0; side < 2; ++side) {                         // algorithms.py:167
@@ -596,7 +615,11 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                         double bd = 0.0; int bk = kNoKey;
                         if (op == 0) scan_two_opt_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
                         else         scan_relocate_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
-                        wave_reduce_best<FI>(bd, bk);
+                        // most one-to-all scans find no improving move: one ballot decides whether the
+                        // three-stage arg-min is needed at all
+                        STAMP_END(1);   // penalty update + position search + o2a scan
+                        if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
+                        STAMP_END(2);   // reduction
                         if (lane == 0) evals += (op == 0) ? (n - 3) : (n - 2);
                         if (bk != kNoKey) {                                    // algorithms.py:175
                             apply_move(s, t, t2, Ef, Eb, n, op, i, bk, lane, kWave, eager_cost);
@@ -611,10 +634,12 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                             } else if (lane == 0) {
                                 tr.len++;                                      // move counted, cost deferred
                             }
+                            STAMP_END(3);   // apply move + reload
                         }
                     }
                 }
                 steps++;
+                STAMP_COUNT(6);
                 if ((steps & 63) == 0) {
                     long long el = wall_clock64() - t_start;
                     if (el > watchdog_ticks) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
@@ -627,6 +652,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
             }
             // tour buffers may have been swapped an odd number of times: publish which one is current
             if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
+            STAMP_END(4);       // phase tail
         }
         __syncthreads();
         {
@@ -636,7 +662,9 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         }
 
         // ---- optimisation (algorithms.py:188) ----
+        STAMP_BEGIN();
         local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);
+        STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
             for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
@@ -653,6 +681,9 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (A.trace_len) A.trace_len[b] = tr.len;
         if (A.evals) A.evals[b] = evals;
         if (A.status) A.status[b] = status;
+#ifdef GLS_STAMPS
+        if (A.trace_time) { long long *o = reinterpret_cast<long long *>(A.trace_time) + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
+#endif
     }
     if (A.penalty_out) {
         int32_t *po = A.penalty_out + (size_t)b * nn;
@@ -771,22 +802,32 @@ size_t gls_lds_bytes(int n, int store, int penalty_bits) {
     return off;
 }
 
-int gls_block_threads(int n) {
+int gls_block_threads(int n, int store) {
     if (n <= 24) return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
+    // compact store, 4 workgroups per CU: measured at TSP100 x 1024 (outer iterations in 2 s)
+    //   8 waves (64 VGPRs, 32 B of scratch in the serial phase) 7.9k | 4 waves (no spills) 6.3k |
+    //   6 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (only 3 resident)
     return 512;
 }
 
-template <class S, bool FI>
-static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    auto kern = gls_kernel<S, FI>;
+template <class S, bool FI, int GP>
+static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    auto kern = gls_kernel<S, FI, GP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B), dim3(threads), lds, stream, A);
     return hipGetLastError();
+}
+
+template <class S, bool FI>
+static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover n <= 128
+    if (A.n <= 2 * kWave) return launch_gls_g<S, FI, 2>(A, lds, threads, stream);
+    return launch_gls_g<S, FI, kGuidePassesMax>(A, lds, threads, stream);
 }
 
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
@@ -814,7 +855,7 @@ hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, 
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
                             bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,
                             hipStream_t stream) {
-    int threads = pos_i ? 64 : gls_block_threads(n);
+    int threads = pos_i ? 64 : gls_block_threads(n, GLS_STORE_GLOBAL);
     (void)hipGetLastError();
     if (first_improvement)
         hipLaunchKernelGGL(best_move_kernel<true>, dim3(B), dim3(threads), 0, stream, tour, D, n, op, pos_i, delta_out, move_out, new_tour);
