@@ -79,6 +79,7 @@ struct TriStore {
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = true;
     static constexpr int kWavesPerSimd = 6;      // 3 workgroups of 8 waves per CU
+    static constexpr int kScanUnroll = 1;        // 80-VGPR budget: no room for batched evaluations
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
         return ((hi * (hi - 1)) >> 1) + lo;
@@ -107,6 +108,7 @@ struct TriDGlobalP {
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
     static constexpr int kWavesPerSimd = 8;      // 4 workgroups of 8 waves per CU (64 VGPRs)
+    static constexpr int kScanUnroll = 1;
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
         return ((hi * (hi - 1)) >> 1) + lo;
@@ -134,6 +136,7 @@ struct GlobalStore {
     using tour_t = int32_t;
     static constexpr bool kPenInLds = false;
     static constexpr int kWavesPerSimd = 4;
+    static constexpr int kScanUnroll = 2;
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
         p[(size_t)a * n + b] += 1;
         p[(size_t)b * n + a] += 1;
@@ -326,41 +329,118 @@ __device__ __forceinline__ void block_reduce_best(Ctl *ctl, int &phase, int wave
 // ---------------------------------------------------------------------------------------------
 // a2a scans on the plain matrix.  Ef[p] = dist(t[p-1], t[p]), Eb[p] = dist(t[p], t[p-1]), p=1..n.
 // ---------------------------------------------------------------------------------------------
-template <class S, bool FI, class TT>
+// Work items of a wavefront = (row i, pass of 64 lanes over j = 1 + 64*pass + lane).  U independent items are
+// evaluated per step, loads first, so their LDS latencies overlap (the descent is latency-bound: one or two
+// wavefronts per SIMD, a chain of dependent ds_reads per evaluation).
+template <class S, bool FI, class TT, int U>
 __device__ __forceinline__ void scan_two_opt_a2a(const S &s, const TT *t, const double *Eb, int n,
                                                  int wave, int nwaves, int lane, double &bd, int &bk) {
-    // itertools.combinations(range(1,n),2), |i-j| >= 2  (operators.py:36-39)
-    for (int i = 1 + wave; i <= n - 3; i += nwaves) {
-        int a = t[i], b = t[i - 1];
-        double eab = Eb[i];                                  // D[a,b]
-        for (int j = i + 2 + lane; j <= n - 1; j += kWave) {
-            int c = t[j], d = t[j - 1];
-            double delta = s.dist(a, c) + s.dist(b, d);
-            delta = delta - eab;
-            delta = delta - Eb[j];                           // D[c,d]
-            consider<FI>(delta, make_key(i, j), bd, bk);
+    // itertools.combinations(range(1,n),2), |i-j| >= 2  (operators.py:36-39): rows i = 1..n-3, j = i+2..n-1
+    if constexpr (U == 1) {      // register-starved variants: plain row loop
+        for (int i = 1 + wave; i <= n - 3; i += nwaves) {
+            const int a = t[i], b = t[i - 1];
+            const double eab = Eb[i];                            // D[a,b]
+            for (int j = i + 2 + lane; j <= n - 1; j += kWave) {
+                const int c = t[j], d = t[j - 1];
+                double delta = s.dist(a, c) + s.dist(b, d);
+                delta = delta - eab;
+                delta = delta - Eb[j];                           // D[c,d]
+                consider<FI>(delta, make_key(i, j), bd, bk);
+            }
+        }
+        return;
+    }
+    const int P = (n - 1 + kWave - 1) / kWave;
+    const int rows = n - 3;
+    const int my_rows = rows > wave ? (rows - wave + nwaves - 1) / nwaves : 0;
+    int r = 0, pass = 0;
+    for (int q0 = 0; q0 < my_rows * P; q0 += U) {
+        int ii[U], jj[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = r < my_rows;
+            const int i = 1 + wave + (live ? r : 0) * nwaves;
+            const int j = 1 + pass * kWave + lane;
+            ok[u] = live && j >= i + 2 && j <= n - 1;
+            ii[u] = i; jj[u] = ok[u] ? j : i + 2;
+            if (++pass == P) { pass = 0; ++r; }
+        }
+        int a[U], b[U], c[U], d[U]; double eab[U], ecd[U], x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = t[ii[u]]; b[u] = t[ii[u] - 1]; c[u] = t[jj[u]]; d[u] = t[jj[u] - 1];
+            eab[u] = Eb[ii[u]]; ecd[u] = Eb[jj[u]];                        // D[a,b], D[c,d]
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { x[u] = s.dist(a[u], c[u]); y[u] = s.dist(b[u], d[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double delta = x[u] + y[u];
+            delta = delta - eab[u];
+            delta = delta - ecd[u];
+            if (ok[u]) consider<FI>(delta, make_key(ii[u], jj[u]), bd, bk);
         }
     }
 }
 
-template <class S, bool FI, class TT>
+template <class S, bool FI, class TT, int U>
 __device__ __forceinline__ void scan_relocate_a2a(const S &s, const TT *t, const double *Ef, int n,
                                                   int wave, int nwaves, int lane, double &bd, int &bk) {
-    // itertools.permutations(range(1,n),2), skip i-j == 1  (operators.py:133-136)
-    for (int i = 1 + wave; i <= n - 1; i += nwaves) {
-        int a = t[i - 1], b = t[i], c = t[i + 1];
-        double base = -Ef[i];                                // -D[a,b]
-        base = base - Ef[i + 1];                             // -D[b,c]
-        base = base + s.dist(a, c);                          // +D[a,c]
-        for (int j = 1 + lane; j <= n - 1; j += kWave) {
-            if (j == i || j == i - 1) continue;
-            int d, e; double de;
-            if (i < j) { d = t[j]; e = t[j + 1]; de = Ef[j + 1]; }
-            else       { d = t[j - 1]; e = t[j]; de = Ef[j]; }
-            double delta = base - de;                        // -D[d,e]
-            delta = delta + s.dist(d, b);
-            delta = delta + s.dist(b, e);
-            consider<FI>(delta, make_key(i, j), bd, bk);
+    // itertools.permutations(range(1,n),2), skip i-j == 1  (operators.py:133-136): rows i = 1..n-1
+    if constexpr (U == 1) {
+        for (int i = 1 + wave; i <= n - 1; i += nwaves) {
+            const int a = t[i - 1], b = t[i], c = t[i + 1];
+            double base = -Ef[i];                                // -D[a,b]
+            base = base - Ef[i + 1];                             // -D[b,c]
+            base = base + s.dist(a, c);                          // +D[a,c]
+            for (int j = 1 + lane; j <= n - 1; j += kWave) {
+                if (j == i || j == i - 1) continue;
+                int d, e; double de;
+                if (i < j) { d = t[j]; e = t[j + 1]; de = Ef[j + 1]; }
+                else       { d = t[j - 1]; e = t[j]; de = Ef[j]; }
+                double delta = base - de;                        // -D[d,e]
+                delta = delta + s.dist(d, b);
+                delta = delta + s.dist(b, e);
+                consider<FI>(delta, make_key(i, j), bd, bk);
+            }
+        }
+        return;
+    }
+    const int P = (n - 1 + kWave - 1) / kWave;
+    const int rows = n - 1;
+    const int my_rows = rows > wave ? (rows - wave + nwaves - 1) / nwaves : 0;
+    int r = 0, pass = 0;
+    for (int q0 = 0; q0 < my_rows * P; q0 += U) {
+        int ii[U], jj[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = r < my_rows;
+            const int i = 1 + wave + (live ? r : 0) * nwaves;
+            const int j = 1 + pass * kWave + lane;
+            ok[u] = live && j <= n - 1 && j != i && j != i - 1;
+            ii[u] = i; jj[u] = ok[u] ? j : (i == n - 1 ? 1 : n - 1);      // any in-range j != i
+            if (++pass == P) { pass = 0; ++r; }
+        }
+        int b[U], d[U], e[U]; double base[U], de[U], x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = ii[u], j = jj[u];
+            const int a = t[i - 1], c = t[i + 1];
+            b[u] = t[i];
+            double bs = -Ef[i];                              // -D[a,b]
+            bs = bs - Ef[i + 1];                             // -D[b,c]
+            base[u] = bs + s.dist(a, c);                     // +D[a,c]
+            if (i < j) { d[u] = t[j]; e[u] = t[j + 1]; de[u] = Ef[j + 1]; }
+            else       { d[u] = t[j - 1]; e[u] = t[j]; de[u] = Ef[j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { x[u] = s.dist(d[u], b[u]); y[u] = s.dist(b[u], e[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double delta = base[u] - de[u];                  // -D[d,e]
+            delta = delta + x[u];
+            delta = delta + y[u];
+            if (ok[u]) consider<FI>(delta, make_key(ii[u], jj[u]), bd, bk);
         }
     }
 }
@@ -369,7 +449,6 @@ __device__ __forceinline__ void scan_relocate_a2a(const S &s, const TT *t, const
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
                                                  int tid, int nthr, double &bd, int &bk) {
-#pragma unroll 2
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         int dj = i - j; if (dj < 0) dj = -dj;
         if (dj < 2) continue;                                // operators.py:61-62
@@ -379,7 +458,6 @@ __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n,
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n, int i,
                                                   int tid, int nthr, double &bd, int &bk) {
-#pragma unroll 2
     for (int j = 1 + tid; j <= n - 1; j += nthr) {
         if (j == i) continue;                                // operators.py:114-115
         consider<FI>(relocate_cost(t, f, i, j), j, bd, bk);
@@ -445,8 +523,8 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
-            if (op == 0) scan_two_opt_a2a<S, FI>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
-            else         scan_relocate_a2a<S, FI>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+            if (op == 0) scan_two_opt_a2a<S, FI, TT, S::kScanUnroll>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+            else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
@@ -806,9 +884,10 @@ int gls_block_threads(int n, int store) {
     if (n <= 24) return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
-    // compact store, 4 workgroups per CU: measured at TSP100 x 1024 (outer iterations in 2 s)
-    //   8 waves (64 VGPRs, 32 B of scratch in the serial phase) 7.9k | 4 waves (no spills) 6.3k |
-    //   6 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (only 3 resident)
+    // compact store, 4 workgroups per CU, measured at TSP100 x 1024 (outer iterations per instance in 2 s):
+    //   8 waves, 64 VGPRs (32 B of scratch in the serial phase)            7.9k   <- used
+    //   4 waves, 128 VGPRs, no spills, descent scans batched 4-deep for ILP  7.4k
+    //   6 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (3 resident only)
     return 512;
 }
 
