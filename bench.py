@@ -79,6 +79,15 @@ def kernel_rooflines(prof, n, B_chunk, n_layers):
         add("gat_aggregate", ["gat_rows"], "mfma", k1_flops, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
     else:
         add("gat_aggregate", ["gat_rows"], "hbm", k1_bytes, PEAK_HBM_GBS, "GB/s")
+    # HBM traffic per launch from the committed PMC passes (profiles/traffic_r01.json: bytes per activation row,
+    # FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch.
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        for name, v in out.items():
+            if name in traffic:
+                v["traffic"] = traffic[name]["hbm_bytes_per_row"] * M
+    except (OSError, ValueError):
+        pass
     if "gat_aggregate" in out:
         t = out["gat_aggregate"]["avg_launch_ms"] * 1e-3
         out["gat_aggregate"]["algorithmic_gbs"] = k1_bytes / t / 1e9
