@@ -378,90 +378,115 @@ __global__ void gat_combine_kernel(const float *__restrict__ part, const float *
 // ---------------------------------------------------------------------------------------------
 // Fused feed-forward block (models.py:26-36,40), one launch per layer:
 //     x  = BN1(h + GATConv(h))          <- log-sum-exp merge of the two attention partials, fused into the
-//                                          staging of the 128-row x tile (never written to HBM)
+//                                          staging of the x tile (never written to HBM)
 //     y  = BN2(x + W2 * ReLU(W1 * x + b1) + b2)
-// One workgroup = 128 rows, 4 waves, wave w owns rows [32w, 32w+32).  The 512-wide hidden layer is
-// processed in 4 chunks of 128 and never leaves the registers: GEMM1 is computed TRANSPOSED,
+// One workgroup = 64 rows, 4 waves, wave w owns rows [16w, 16w+16); two workgroups per CU (74 KB of LDS each)
+// so the memory phases of one overlap the MFMA phases of the other.  The 512-wide hidden layer is processed
+// in 4 chunks of 128 and never leaves the registers: GEMM1 is computed TRANSPOSED on v_mfma_f32_16x16x4_f32,
 //     Hc^T[hid x rows] = W1c[hid x K] * x^T[K x rows]      (A = W1 tile from LDS, B = x tile from LDS)
-// so that in the accumulator the data row sits on the lane and the hidden index in the register; those
-// registers are then fed directly as the B operand of
+// so that in the accumulator the data row sits on the lane (col = lane&15) and the hidden index in
+// (lane>>4, register): hid = 16*ht + 4*(lane>>4) + reg.  Those registers are then fed directly as the B operand of
 //     Y^T[out x rows] += W2c[out x hid] * Hc^T[hid x rows] (A = W2 tile from LDS, B = accumulator registers)
-// with the k order of W2 permuted to the accumulator's row map (k pair of one MFMA = {hmap(r,0), hmap(r,1)}).
+// (the MFMA's k sub-index IS lane>>4, so register `reg` of tile ht pairs with W2 column 16*ht + 4*(lane>>4) + reg).
+// The k order inside GEMM1 is permuted the same way (lane group q walks k = 16*blk + 4*q + s, s = 0..3) so that ONE
+// ds_read_b128 feeds four MFMA steps for A and for B; every product a[k]*b[k] is still formed exactly once.
 // Weight tiles (128 x 32 fp32 = 16 KB) stream L2 -> registers -> LDS through a 2-deep ring, one barrier per
-// tile, 64 MFMAs (4096 cycles) per wave between barriers.  LDS: x tile 66 KB + 2 weight buffers 33.8 KB.
+// tile, 64 MFMAs (2048 cycles) per wave between barriers.
 // ---------------------------------------------------------------------------------------------
-constexpr int FT_M = 128;            // rows per workgroup
-constexpr int LDX = 129;             // x tile row stride (floats): "32 rows at fixed k" reads are conflict-free
-constexpr int LDW = 33;              // weight tile row stride
-
-__device__ __forceinline__ int hmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+constexpr int FT_M = 64;             // rows per workgroup
+constexpr int LDX = 132;             // x tile row stride (floats): 16-B aligned rows; a ds_read_b128 of 16 consecutive
+                                     // rows at one k offset touches 16 disjoint groups of 4 banks (132 = 4 mod 64)
+constexpr int LDW = 36;              // weight tile row stride (36*r mod 64 hits every multiple of 4 once per 16 rows)
 
 template <int SUB>
-__device__ __forceinline__ void ffn_gemm1_stage(f32x16 (&accH)[4], const float *Xs, const float *Wt, int wrow, int lr, int lk) {
+__device__ __forceinline__ void ffn_gemm1_stage(f32x4 (&accH)[8], const float *Xs, const float *Wt, int wrow, int lr, int lq) {
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-        const float b = Xs[(wrow + lr) * LDX + SUB * 32 + kk + lk];
+    for (int blk = 0; blk < 2; ++blk) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(Xs + (wrow + lr) * LDX + SUB * 32 + 16 * blk + 4 * lq);
+        f32x4 a[8];
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            const float a = Wt[(ht * 32 + lr) * LDW + kk + lk];
-            accH[ht] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accH[ht], 0, 0, 0);
-        }
+        for (int ht = 0; ht < 8; ++ht) a[ht] = *reinterpret_cast<const f32x4 *>(Wt + (ht * 16 + lr) * LDW + 16 * blk + 4 * lq);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int ht = 0; ht < 8; ++ht)
+                accH[ht] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ht][st], b[st], accH[ht], 0, 0, 0);
     }
 }
 
 template <int SUB>
-__device__ __forceinline__ void ffn_gemm2_stage(f32x16 (&accY)[4], const f32x16 (&accH)[4], const float *Wt, int lr, int lk) {
+__device__ __forceinline__ void ffn_gemm2_stage(f32x4 (&accY)[8], const f32x4 (&accH)[8], const float *Wt, int lr, int lq) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float b = accH[SUB][r];
-        const int hm = hmap(r, lk);
+    for (int hh = 0; hh < 2; ++hh) {            // the two 16-wide hidden tiles covered by this 32-wide W2 tile
+        f32x4 a[8];
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            const float a = Wt[(ot * 32 + lr) * LDW + hm];
-            accY[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accY[ot], 0, 0, 0);
+        for (int ot = 0; ot < 8; ++ot) a[ot] = *reinterpret_cast<const f32x4 *>(Wt + (ot * 16 + lr) * LDW + 16 * hh + 4 * lq);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float b = accH[2 * SUB + hh][st];
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot)
+                accY[ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ot][st], b, accY[ot], 0, 0, 0);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void ffn_fused_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
-                                                        const float *__restrict__ hin,
-                                                        const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
-                                                        const float *__restrict__ W1, const float *__restrict__ b1,
-                                                        const float *__restrict__ W2, const float *__restrict__ b2,
-                                                        const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
-                                                        float *__restrict__ hout, long M) {
+__global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
+                                                           const float *__restrict__ hin,
+                                                           const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
+                                                           const float *__restrict__ W1, const float *__restrict__ b1,
+                                                           const float *__restrict__ W2, const float *__restrict__ b2,
+                                                           const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
+                                                           float *__restrict__ hout, long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *Xs = reinterpret_cast<float *>(smem_raw);        // [128][LDX]
+    float *Xs = reinterpret_cast<float *>(smem_raw);        // [64][LDX]
     float *Wb0 = Xs + FT_M * LDX;                           // [128][LDW]
     float *Wb1 = Wb0 + 128 * LDW;
+    float *vecs = Wb1 + 128 * LDW;                          // b1[512] b2[128] bn2_s[128] bn2_b[128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lr = lane & 31, lk = lane >> 5;
-    const int wrow = wave * 32;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wrow = wave * 16;
     const long row0 = (long)blockIdx.x * FT_M;
 
+    for (int q = tid; q < 512; q += 256) vecs[q] = b1[q];
+    if (tid < 128) { vecs[512 + tid] = b2[tid]; vecs[640 + tid] = bn2_s[tid]; vecs[768 + tid] = bn2_b[tid]; }
+
     // ---- stage the x tile: x = BN1(h + merge(partials))  (gat_combine fused; models.py:15,24,28) ----
-    for (int it = 0; it < (FT_M * 32) / 256; ++it) {
-        const int idx = it * 256 + tid;
-        const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
-        const long m = row0 + row;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (m < M) {
-            const float *ms0 = part_ms + m * (2 * kH), *ms1 = part_ms + (M + m) * (2 * kH);
-            const float m0 = ms0[hd], s0 = ms0[kH + hd], m1 = ms1[hd], s1 = ms1[kH + hd];
-            const float mx = m0 > m1 ? m0 : m1;
-            const float a0 = __expf(m0 - mx), a1 = __expf(m1 - mx);
-            const float inv = 1.f / (s0 * a0 + s1 * a1);
-            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(part + m * kD + c);
-            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(part + (M + m) * kD + c);
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(hin + m * kD + c);
+    // 8 float4 slots per thread, loaded in batches of 4 (all loads of a batch in flight together)
+    constexpr int PB = 4;
+    for (int it0 = 0; it0 < (FT_M * 32) / 256; it0 += PB) {
+        f32x4 p0[PB], p1[PB], hv[PB];
+        float m0[PB], s0[PB], m1[PB], s1[PB];
+        bool live[PB];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float g = (p0[u] * a0 + p1[u] * a1) * inv;
-                o[u] = (hv[u] + g) * bn1_s[c + u] + bn1_b[c + u];
-            }
+        for (int u = 0; u < PB; ++u) {
+            const int idx = (it0 + u) * 256 + tid;
+            const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
+            const long m = row0 + row;
+            live[u] = m < M;
+            const long mc = live[u] ? m : 0;
+            const float *ms0 = part_ms + mc * (2 * kH), *ms1 = part_ms + (M + mc) * (2 * kH);
+            m0[u] = ms0[hd]; s0[u] = ms0[kH + hd]; m1[u] = ms1[hd]; s1[u] = ms1[kH + hd];
+            p0[u] = *reinterpret_cast<const f32x4 *>(part + mc * kD + c);
+            p1[u] = *reinterpret_cast<const f32x4 *>(part + (M + mc) * kD + c);
+            hv[u] = *reinterpret_cast<const f32x4 *>(hin + mc * kD + c);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Xs[row * LDX + c + u] = o[u];
+        for (int u = 0; u < PB; ++u) {
+            const int idx = (it0 + u) * 256 + tid;
+            const int row = idx >> 5, c = (idx & 31) * 4;
+            const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
+            const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
+            const float inv = 1.f / (s0[u] * a0 + s1[u] * a1);
+            f32x4 o4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float g = (p0[u][v] * a0 + p1[u][v] * a1) * inv;
+                const float o = (hv[u][v] + g) * bn1_s[c + v] + bn1_b[c + v];
+                o4[v] = live[u] ? o : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(Xs + row * LDX + c) = o4;
+        }
     }
 
     // ---- weight tile stream: tile t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1, 1: W2), sub = t&3 ----
@@ -476,19 +501,15 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const float *__restrict_
     };
     auto lstore = [&](float *Wt) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Wt[srow * LDW + sk + 4 * u + c] = rw[u][c];
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<f32x4 *>(Wt + srow * LDW + sk + 4 * u) = rw[u];
     };
     gload(0);
     lstore(Wb0);
     __syncthreads();
 
-    f32x16 accY[4], accH[4];
+    f32x4 accY[8], accH[8];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accY[a][r] = 0.f;
+    for (int a = 0; a < 8; ++a) accY[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define FFN_STAGE(S, BODY)                                                                  \
     {                                                                                       \
@@ -504,47 +525,45 @@ __global__ __launch_bounds__(256) void ffn_fused_kernel(const float *__restrict_
     for (int c = 0; c < 4; ++c) {
         // hidden pre-activations start at the bias (C-in of the MFMA chain), models.py:30
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
+        for (int ht = 0; ht < 8; ++ht) accH[ht] = *reinterpret_cast<const f32x4 *>(vecs + c * 128 + ht * 16 + 4 * lq);
+        FFN_STAGE(0, (ffn_gemm1_stage<0>(accH, Xs, Wt, wrow, lr, lq)))
+        FFN_STAGE(1, (ffn_gemm1_stage<1>(accH, Xs, Wt, wrow, lr, lq)))
+        FFN_STAGE(2, (ffn_gemm1_stage<2>(accH, Xs, Wt, wrow, lr, lq)))
+        FFN_STAGE(3, (ffn_gemm1_stage<3>(accH, Xs, Wt, wrow, lr, lq)))
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accH[ht][r] = b1[c * 128 + ht * 32 + hmap(r, lk)];
-        FFN_STAGE(0, (ffn_gemm1_stage<0>(accH, Xs, Wt, wrow, lr, lk)))
-        FFN_STAGE(1, (ffn_gemm1_stage<1>(accH, Xs, Wt, wrow, lr, lk)))
-        FFN_STAGE(2, (ffn_gemm1_stage<2>(accH, Xs, Wt, wrow, lr, lk)))
-        FFN_STAGE(3, (ffn_gemm1_stage<3>(accH, Xs, Wt, wrow, lr, lk)))
+        for (int ht = 0; ht < 8; ++ht)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accH[ht][r] = accH[ht][r] > 0.f ? accH[ht][r] : 0.f;   // ReLU, models.py:31
-        FFN_STAGE(4, (ffn_gemm2_stage<0>(accY, accH, Wt, lr, lk)))
-        FFN_STAGE(5, (ffn_gemm2_stage<1>(accY, accH, Wt, lr, lk)))
-        FFN_STAGE(6, (ffn_gemm2_stage<2>(accY, accH, Wt, lr, lk)))
-        FFN_STAGE(7, (ffn_gemm2_stage<3>(accY, accH, Wt, lr, lk)))
+            for (int r = 0; r < 4; ++r) accH[ht][r] = accH[ht][r] > 0.f ? accH[ht][r] : 0.f;   // ReLU, models.py:31
+        FFN_STAGE(4, (ffn_gemm2_stage<0>(accY, accH, Wt, lr, lq)))
+        FFN_STAGE(5, (ffn_gemm2_stage<1>(accY, accH, Wt, lr, lq)))
+        FFN_STAGE(6, (ffn_gemm2_stage<2>(accY, accH, Wt, lr, lq)))
+        FFN_STAGE(7, (ffn_gemm2_stage<3>(accY, accH, Wt, lr, lq)))
     }
 #undef FFN_STAGE
 
     // ---- epilogue: y = BN2(x + (acc + b2)); transposed accumulator -> x tile in LDS -> coalesced rows ----
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) {
+    for (int ot = 0; ot < 8; ++ot) {
+        const int out = ot * 16 + 4 * lq;
+        float *xp = Xs + (wrow + lr) * LDX + out;
+        f32x4 x = *reinterpret_cast<const f32x4 *>(xp);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(vecs + 512 + out);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(vecs + 640 + out);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(vecs + 768 + out);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int out = ot * 32 + hmap(r, lk);
-            float *xp = Xs + (wrow + lr) * LDX + out;
-            float v = accY[ot][r] + b2[out];          // Linear2 output (models.py:32)
-            v = *xp + v;                              // x + y            (models.py:15)
-            *xp = v * bn2_s[out] + bn2_b[out];        // BatchNorm1d eval (models.py:35)
+        for (int r = 0; r < 4; ++r) {
+            float v = accY[ot][r] + bb[r];            // Linear2 output (models.py:32)
+            v = x[r] + v;                             // x + y            (models.py:15)
+            x[r] = v * sc[r] + sh[r];                 // BatchNorm1d eval (models.py:35)
         }
+        *reinterpret_cast<f32x4 *>(xp) = x;
     }
     __syncthreads();
     for (int it = 0; it < (FT_M * 32) / 256; ++it) {
         const int idx = it * 256 + tid;
         const int row = idx >> 5, c = (idx & 31) * 4;
         const long m = row0 + row;
-        if (m < M) {
-            f32x4 o;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) o[u] = Xs[row * LDX + c + u];
-            *reinterpret_cast<f32x4 *>(hout + m * kD + c) = o;
-        }
+        if (m < M) *reinterpret_cast<f32x4 *>(hout + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
     }
 }
 
@@ -634,7 +653,7 @@ hipError_t launch_gat_combine(const float *part, const float *part_ms, const flo
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
-    const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW) * sizeof(float);
+    const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW + 896) * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
