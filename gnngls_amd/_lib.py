@@ -35,7 +35,7 @@ SIGNATURES = {
     "gnngls_profile_collect": [_vp, _vp],
 }
 
-PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine", "gemm_ffn1", "gemm_ffn2",
+PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine(unused)", "gemm_ffn1(unused)", "gemm_ffn2(unused)",
               "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls", "ffn_fused"]
 
 

@@ -15,8 +15,6 @@ hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M
                        const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st);
 hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
                            float *part_ms, hipStream_t st);
-hipError_t launch_gat_combine(const float *part, const float *part_ms, const float *h, const float *bn_scale,
-                              const float *bn_shift, float *out, long M, hipStream_t st);
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st);

@@ -16,7 +16,7 @@
 //                           LDS (n=100: 50.7 KB), every destination {i,j} streams over that tile;
 //                           el/er are recomputed from the LDS tile (no [N,8] tensors in HBM); the
 //                           softmax shift is the exact row maximum (top-2 trick excludes k=j)
-//       gat_combine_kernel: log-sum-exp merge of the two row partials of a destination + skip + BN1
+//       (the log-sum-exp merge of the two row partials + skip + BN1 is fused into ffn_fused_kernel)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -347,34 +347,6 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
     }
 }
 
-// merge the two row partials of every node, add the skip input and apply BatchNorm #1 (eval):
-//   h1 = BN1(h + GATConv(h))      models.py:15,24,28
-__global__ void gat_combine_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
-                                   const float *__restrict__ h, const float *__restrict__ bn_scale,
-                                   const float *__restrict__ bn_shift, float *__restrict__ out, long M) {
-    const long total = M * (kD / 4);
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const long m = q >> 5;
-        const int c = (int)(q & 31) * 4, hd = c >> 4;
-        const float *ms0 = part_ms + m * (2 * kH), *ms1 = part_ms + (M + m) * (2 * kH);
-        float m0 = ms0[hd], s0 = ms0[kH + hd], m1 = ms1[hd], s1 = ms1[kH + hd];
-        float mx = m0 > m1 ? m0 : m1;
-        float a0 = __expf(m0 - mx), a1 = __expf(m1 - mx);
-        float inv = 1.f / (s0 * a0 + s1 * a1);
-        f32x4 p0 = *reinterpret_cast<const f32x4 *>(part + m * kD + c);
-        f32x4 p1 = *reinterpret_cast<const f32x4 *>(part + (M + m) * kD + c);
-        f32x4 hv = *reinterpret_cast<const f32x4 *>(h + m * kD + c);
-        f32x4 o;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float g = (p0[u] * a0 + p1[u] * a1) * inv;
-            float v = hv[u] + g;
-            o[u] = v * bn_scale[c + u] + bn_shift[c + u];
-        }
-        *reinterpret_cast<f32x4 *>(out + m * kD + c) = o;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Fused feed-forward block (models.py:26-36,40), one launch per layer:
 //     x  = BN1(h + GATConv(h))          <- log-sum-exp merge of the two attention partials, fused into the
@@ -640,13 +612,6 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(256), lds, st, ft, attn_l, attn_r, n, part, part_ms);
-    return hipGetLastError();
-}
-
-hipError_t launch_gat_combine(const float *part, const float *part_ms, const float *h, const float *bn_scale,
-                              const float *bn_shift, float *out, long M, hipStream_t st) {
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_combine_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, part, part_ms, h, bn_scale, bn_shift, out, M);
     return hipGetLastError();
 }
 
