@@ -99,41 +99,41 @@ int gnngls_gls_resident_capacity(int n) {
 }
 
 int gnngls_two_opt_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!tour || !D || !out || B < 0 || n < 3) return fail(GNNGLS_ERR_ARG, "two_opt_delta_all: bad argument");
-    if (B == 0) return GNNGLS_OK;
     hipError_t e = gnngls::launch_delta_all(tour, D, B, n, 0, out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "two_opt_delta_all");
 }
 
 int gnngls_relocate_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!tour || !D || !out || B < 0 || n < 3) return fail(GNNGLS_ERR_ARG, "relocate_delta_all: bad argument");
-    if (B == 0) return GNNGLS_OK;
     hipError_t e = gnngls::launch_delta_all(tour, D, B, n, 1, out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "relocate_delta_all");
 }
 
 int gnngls_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
                      int first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!tour || !D || !delta_out || !move_out || B < 0 || n < 3 || (op != 0 && op != 1) || n > 65535)
         return fail(GNNGLS_ERR_ARG, "best_move: bad argument");
-    if (B == 0) return GNNGLS_OK;
     hipError_t e = gnngls::launch_best_move(tour, D, B, n, op, pos_i, first_improvement != 0, delta_out, move_out,
                                             new_tour, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "best_move");
 }
 
 int gnngls_tour_cost(const int32_t *tour, const double *D, int B, int n, double *cost_out, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!tour || !D || !cost_out || B < 0 || n < 1) return fail(GNNGLS_ERR_ARG, "tour_cost: bad argument");
-    if (B == 0) return GNNGLS_OK;
     ProfScope ps(GNNGLS_PROF_TOUR_COST, (hipStream_t)stream);
     hipError_t e = gnngls::launch_tour_cost(tour, D, B, n, cost_out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "tour_cost");
 }
 
 int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *tour_out, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!W || !tour_out || B < 0 || n < 1 || depot < 0 || depot >= n)
         return fail(GNNGLS_ERR_ARG, "nearest_neighbor: bad argument");
-    if (B == 0) return GNNGLS_OK;
     ProfScope ps(GNNGLS_PROF_NEAREST_NEIGHBOR, (hipStream_t)stream);
     hipError_t e = gnngls::launch_nearest_neighbor(W, B, n, depot, tour_out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "nearest_neighbor");
@@ -146,6 +146,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
                    int32_t *best_tour, double *best_cost, int64_t *outer_iters,
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
                    int32_t *penalty_out, int64_t *evals_out, int32_t *status, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!D || !init_tour || !init_cost || !best_tour || !best_cost || B < 0 || n < 3 || n > 65535 || trace_cap < 0)
         return fail(GNNGLS_ERR_ARG, "gls_run: bad argument");
     if (max_outer_iters != 0 && (!guides || n_guides < 1))
@@ -153,7 +154,6 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (!(watchdog_s > 0.0)) return fail(GNNGLS_ERR_ARG, "gls_run: watchdog_s must be > 0");
     if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32)
         return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16 or 32");
-    if (B == 0) return GNNGLS_OK;
     hipStream_t st = (hipStream_t)stream;
     gnngls::GlsArgs A;
     memset(&A, 0, sizeof(A));
@@ -210,13 +210,13 @@ int64_t gnngls_regret_forward_workspace_bytes(int B, int n) {
 
 int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
                           float *y_out, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!feat || !weights || !y_out || !workspace || B < 0 || n < 3 || in_dim < 1 || n_layers < 0)
         return fail(GNNGLS_ERR_ARG, "regret_forward: bad argument");
     if ((in_dim * 128) % 4 != 0) return fail(GNNGLS_ERR_UNSUPPORTED, "regret_forward: in_dim*128 must be a multiple of 4");
     if (gnngls::gat_rows_lds_bytes(n) > kLdsPerCU)
         return fail(GNNGLS_ERR_UNSUPPORTED, "regret_forward: n=%d needs %zu B of LDS per row tile (> 160 KiB)", n,
                     gnngls::gat_rows_lds_bytes(n));
-    if (B == 0) return GNNGLS_OK;
     const long N = (long)n * (n - 1) / 2;
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     int64_t avail = workspace_bytes - (int64_t)(base - (uintptr_t)workspace);
@@ -264,16 +264,16 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
 }
 
 int gnngls_pack_features(const double *D, int B, int n, double scale, double min_, float *feat, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!D || !feat || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "pack_features: bad argument");
-    if (B == 0) return GNNGLS_OK;
     ProfScope ps(GNNGLS_PROF_PACK, (hipStream_t)stream);
     hipError_t e = gnngls::launch_pack_features(D, B, n, scale, min_, feat, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "pack_features");
 }
 
 int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_, double *out, void *stream) {
+    if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!y || !out || B < 0 || n < 2) return fail(GNNGLS_ERR_ARG, "unpack_regret: bad argument");
-    if (B == 0) return GNNGLS_OK;
     ProfScope ps(GNNGLS_PROF_UNPACK, (hipStream_t)stream);
     hipError_t e = gnngls::launch_unpack_regret(y, B, n, scale, min_, out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "unpack_regret");

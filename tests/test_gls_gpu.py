@@ -231,3 +231,81 @@ def test_gls_penalty16_overflow_is_detected_and_rerun(ops):
     assert_bits(r.trace_cost[0, :len(g["trace"])].cpu().numpy(), g["trace"])
     assert r.best_tour[0].cpu().tolist() == g["best_tour"].tolist()
     assert np.array_equal(r.penalty[0].cpu().numpy(), g["penalty"])
+
+
+@pytest.mark.parametrize("n,B,K,fi", [(3, 8, 0, False), (4, 8, 5, False), (5, 8, 5, True), (48, 6, 4, True), (100, 4, 3, True)])
+def test_gls_tiny_and_first_improvement_vs_oracle(ops, n, B, K, fi):
+    """Smallest legal instances and first_improvement=True.  n=3 has a single tour (no 2-opt move, one relocate
+    pair): only the descent is run there -- the perturbation loop of the reference (`while moves <
+    perturbation_moves`, algorithms.py:151) can never accept a move on a 3-cycle and does not terminate."""
+    from oracle import gls_oracle as go
+    rng = np.random.default_rng(77 + n)
+    D, _ = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=5, first_improvement=fi, max_outer_iters=K,
+                    trace_cap=4096, want_penalty=True)
+    for b in range(B):
+        o = go.guided_local_search(D[b], D[b][None], init[b].cpu().numpy(), cost[b].item(), perturbation_moves=5,
+                                   first_improvement=fi, max_outer_iters=K)
+        assert int(r.status[b]) == 0
+        assert int(r.trace_len[b]) == o["trace_len"]
+        assert_bits(r.trace_cost[b, :o["trace_len"]].cpu().numpy(), o["trace"])
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"])
+
+
+def test_gls_long_run_compact_store_vs_oracle(ops):
+    """TSP100 on the compact store (penalties in L2): 150 outer iterations, ~4500 accepted moves, penalties in
+    the tens -- every accepted move, the best tour and the final penalty matrix equal the CPU oracle's."""
+    from oracle import gls_oracle as go
+    n, B, K = 100, 2, 150
+    assert ops.gls_resident_capacity(n) == 1024
+    rng = np.random.default_rng(2024)
+    D, _ = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=1 << 15,
+                    want_penalty=True)
+    for b in range(B):
+        o = go.guided_local_search(D[b], D[b][None], init[b].cpu().numpy(), cost[b].item(), perturbation_moves=20,
+                                   max_outer_iters=K)
+        L = o["trace_len"]
+        assert L > 3000 and int(r.trace_len[b]) == L
+        assert_bits(r.trace_cost[b, :L].cpu().numpy(), o["trace"])
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"]) and o["penalty"].max() >= 5
+
+
+def test_empty_batches_are_noops(ops):
+    d = torch.zeros((0, 5, 5), dtype=torch.float64, device="cuda")
+    t = torch.zeros((0, 6), dtype=torch.int32, device="cuda")
+    assert ops.tour_cost(t, d).shape == (0,)
+    assert ops.nearest_neighbor(d).shape == (0, 6)
+    assert ops.two_opt_delta_all(t, d).shape == (0, 6, 6)
+    r = ops.gls_run(d, None, t, torch.zeros((0,), dtype=torch.float64, device="cuda"), max_outer_iters=0)
+    assert r.best_tour.shape == (0, 6)
+
+
+def test_full_size_batch_properties(ops):
+    """BASELINE configs[2] size (TSP100 x 1024, all resident): every result is a valid tour whose recomputed
+    cost equals the reported cost, no instance is worse than plain local search, no watchdog aborts."""
+    n, B = 100, 1024
+    D, _ = random_instances(np.random.default_rng(11), B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    ls = ops.gls_run(d, None, init, cost, max_outer_iters=0)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0)
+    t1.record(); torch.cuda.synchronize()
+    assert t0.elapsed_time(t1) < 1500.0          # one round: all 1024 workgroups were resident together
+    assert (r.status == 0).all() and (r.outer_iters > 100).all()
+    assert (r.best_cost <= ls.best_cost).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
+    assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all()
+    assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
