@@ -125,10 +125,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(n_dev, 1))
     import torch.distributed as dist
+    # backend "nccl" is RCCL on ROCm; GNNGLS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box
+    # with fewer GPUs than ranks (the gather then goes through host memory)
+    backend = os.environ.get("GNNGLS_DIST_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
 
     from gnngls_amd import _lib, ops, parallel, pipeline
     from gnngls_amd.synthetic import random_instances
@@ -160,7 +167,11 @@ def main():
         best_known = torch.minimum(best_known, r.best_cost)
         local = torch.stack([r.best_cost, r.init_cost, r.outer_iters.double(), r.evals.double(),
                              r.status.double()], dim=1).contiguous()           # [B, 5] fp64
-        gathered = parallel.gather_results(local)                              # the one collective of the path
+        if world > 1 and backend != "nccl":
+            g = parallel.gather_results(local.cpu())
+            gathered = g.cuda() if g is not None else None
+        else:
+            gathered = parallel.gather_results(local)                          # the one collective of the path
         return r
 
     for _ in range(args.warmup):
@@ -176,7 +187,7 @@ def main():
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
