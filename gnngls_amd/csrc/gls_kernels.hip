@@ -492,13 +492,17 @@ __device__ __forceinline__ void build_edges(const S &s, const TT *t, double *Ef,
 // [exact] tour_cost (__init__.py:17-21): c = 0; c += w left to right.  Ef must be current.
 __device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) {
     double c = 0.0;
-    for (int p = 1; p <= n; ++p) c += Ef[p];
+#pragma unroll 8
+    for (int p = 1; p <= n; ++p) c += Ef[p];      // the adds stay in order; the LDS reads of 8 steps overlap
     return c;
 }
 
 // ---------------------------------------------------------------------------------------------
 // The persistent GLS kernel
 // ---------------------------------------------------------------------------------------------
+// Search trace (algorithms.py:127-130,180-183).  TR=false (trace_cap == 0, the throughput path) keeps only the
+// accepted-move counter: no pointers, no clock, and the per-move tour_cost is deferred (see header).
+template <bool TR>
 struct Trace {
     double *cost; float *time; int cap; int len; long long t0;
     __device__ __forceinline__ void push(double c) {
@@ -509,10 +513,15 @@ struct Trace {
         len++;
     }
 };
+template <>
+struct Trace<false> {
+    int len;
+    __device__ __forceinline__ void push(double) { len++; }
+};
 
-template <class S, bool FI, class TT>
+template <class S, bool FI, class TT, class TRC>
 __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
-                                 Ctl *ctl, int &phase, double &cur_cost, Trace &tr, long long &evals) {
+                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
     build_edges(s, t, Ef, Eb, n, tid, nthr);
@@ -541,7 +550,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 
 // launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
 // CU at n=100 need <= 80 VGPRs), 4 for the global-memory fallback.
-template <class S, bool FI, int GP>
+template <class S, bool FI, int GP, bool TR>
 __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -588,12 +597,14 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     __syncthreads();
 
     const long long t_start = wall_clock64();
-    Trace tr;
-    tr.cap = A.trace_cap; tr.len = 0; tr.t0 = t_start;
-    tr.cost = A.trace_cost ? A.trace_cost + (size_t)b * A.trace_cap : nullptr;
-    tr.time = A.trace_time ? A.trace_time + (size_t)b * A.trace_cap : nullptr;
-    if (!tr.cost) tr.cap = 0;
-    const bool eager_cost = tr.cap > 0;
+    Trace<TR> tr;
+    tr.len = 0;
+    if constexpr (TR) {
+        tr.cap = A.trace_cap; tr.t0 = t_start;
+        tr.cost = A.trace_cost + (size_t)b * A.trace_cap;
+        tr.time = A.trace_time ? A.trace_time + (size_t)b * A.trace_cap : nullptr;
+    }
+    constexpr bool eager_cost = TR;
 
     const double init_cost = A.init_cost[b];
     const double k = 0.1 * init_cost / (double)n;                             // algorithms.py:137
@@ -608,8 +619,6 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
     __syncthreads();
 
-    const long long limit_ticks = (long long)(A.time_limit_s * 1e8);
-    const long long watchdog_ticks = (long long)(A.watchdog_s * 1e8);
     long long iter_i = 0;
     const GuidedDist<S> gd{s, k};
 
@@ -619,8 +628,8 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
             long long el = wall_clock64() - t_start;
             int go;
             if (A.max_outer_iters >= 0) go = iter_i < A.max_outer_iters;
-            else go = el < limit_ticks;
-            if (el > watchdog_ticks) { go = 0; status = GNNGLS_STATUS_WATCHDOG_DEV; }
+            else go = el < (long long)(A.time_limit_s * 1e8);
+            if (el > (long long)(A.watchdog_s * 1e8)) { go = 0; status = GNNGLS_STATUS_WATCHDOG_DEV; }
             if (status != 0) go = 0;
             ctl->flag = go;
         }
@@ -631,6 +640,9 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
         if (wave == 0) {
             STAMP_BEGIN();
+            // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
+            // waves of the other resident workgroups on the same SIMD: give it priority while it runs
+            __builtin_amdgcn_s_setprio(3);
             int moves = 0;
             bool any_moved = false;
             long long steps = 0;
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                 STAMP_COUNT(6);
                 if ((steps & 63) == 0) {
                     long long el = wall_clock64() - t_start;
-                    if (el > watchdog_ticks) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
+                    if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
                 }
             }
             if (any_moved && !eager_cost) {
@@ -730,6 +742,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
             }
             // tour buffers may have been swapped an odd number of times: publish which one is current
             if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
+            __builtin_amdgcn_s_setprio(0);
             STAMP_END(4);       // phase tail
         }
         __syncthreads();
@@ -760,7 +773,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (A.evals) A.evals[b] = evals;
         if (A.status) A.status[b] = status;
 #ifdef GLS_STAMPS
-        if (A.trace_time) { long long *o = reinterpret_cast<long long *>(A.trace_time) + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
+        if (A.outer_iters) { long long *o = reinterpret_cast<long long *>(A.outer_iters) + (size_t)A.B + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
 #endif
     }
     if (A.penalty_out) {
@@ -891,15 +904,22 @@ int gls_block_threads(int n, int store) {
     return 512;
 }
 
-template <class S, bool FI, int GP>
-static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    auto kern = gls_kernel<S, FI, GP>;
+template <class S, bool FI, int GP, bool TR>
+static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    auto kern = gls_kernel<S, FI, GP, TR>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(A.B), dim3(threads), lds, stream, A);
     return hipGetLastError();
+}
+
+template <class S, bool FI, int GP>
+static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    // trace_cap == 0 (no trace buffer): the trace-free instantiation (fewer live registers in the serial phase)
+    if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true>(A, lds, threads, stream);
+    return launch_gls_k<S, FI, GP, false>(A, lds, threads, stream);
 }
 
 template <class S, bool FI>

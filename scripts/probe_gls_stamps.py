@@ -6,15 +6,19 @@ import torch
 sys.path.insert(0, ".")
 from gnngls_amd import ops
 from gnngls_amd.synthetic import random_instances
+import os
+os.environ['GNNGLS_STAMPS'] = '1'
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()
 init = ops.nearest_neighbor(D); cost = ops.tour_cost(init, D)
-# trace_time buffer doubles as the stamp sink: needs trace_cap >= 16 floats (= 8 int64) per instance; trace_cost must exist
+# GNNGLS_STAMPS=1 makes ops.gls_run allocate 8 extra int64 per instance behind outer_iters (the stamp sink);
+# trace_cap=0 = the throughput path (trace-free kernel instantiation, deferred tour_cost)
+tc = int(os.environ.get("TRACE_CAP", "0"))
 r = ops.gls_run(D, D[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
-                trace_cap=16, want_trace_time=True)
+                trace_cap=tc)
 torch.cuda.synchronize()
-st = r.trace_time.view(torch.int64).double().mean(0).cpu().numpy()
+st = r.stamps.double().mean(0).cpu().numpy()
 names = ["utility argmax", "o2a scan (+pen, pos search)", "o2a reduce", "apply+reload", "phase tail", "descent (LS)", "steps"]
 tot = st[:6].sum()
 it = r.outer_iters.double().mean().item()
