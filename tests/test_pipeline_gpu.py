@@ -1,0 +1,84 @@
+"""GPU tests of the batched end-to-end path (gnngls_amd.pipeline) and size-independent properties of the forward
+at sizes where the CPU oracle is too slow (TSP100 x many, TSP200)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def fbits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from gnngls_amd import pipeline
+    return pipeline.synthetic_model(seed=7)
+
+
+def test_solve_batch_matches_oracle_chain(model):
+    """features -> forward -> regret -> nearest_neighbor -> tour_cost -> guided_local_search, K outer iterations:
+    the search part is bit-exact against the CPU oracle fed with the GPU's own regret predictions."""
+    from gnngls_amd import pipeline
+    from gnngls_amd.synthetic import random_instances
+    from oracle import gls_oracle as go
+    n, B, K = 30, 6, 4
+    D_host, _ = random_instances(np.random.default_rng(3), B, n)
+    D = torch.from_numpy(D_host).cuda()
+    sc = pipeline.Scalers.fit_weights(D)
+    r = pipeline.solve_batch(D, model, sc, guides=("regret_pred", "weight"), max_outer_iters=K, perturbation_moves=20,
+                             trace_cap=4096, keep_regret=True)
+    R = r.regret_pred.cpu().numpy()
+    assert (R >= 0).all() and np.array_equal(R, R.transpose(0, 2, 1))
+    for b in range(B):
+        init = go.nearest_neighbor(R[b])
+        cost = go.tour_cost(init, D_host[b])
+        assert fbits(r.init_cost[b].item()) == fbits(cost)
+        o = go.guided_local_search(D_host[b], np.stack([R[b], D_host[b]]), init, cost, perturbation_moves=20,
+                                   max_outer_iters=K)
+        L = o["trace_len"]
+        assert int(r.moves[b]) == L
+        assert np.array_equal(fbits(r.trace_cost[b, :L].cpu().numpy()), fbits(o["trace"]))
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert fbits(r.best_cost[b].item()) == fbits(o["best_cost"])
+
+
+def test_solve_batch_chunking_and_weight_guide(model):
+    """A batch larger than the chunk size is processed in chunks with identical results; guides=['weight'] needs no model."""
+    from gnngls_amd import pipeline
+    from gnngls_amd.synthetic import random_instances
+    n, B = 20, 10
+    D = torch.from_numpy(random_instances(np.random.default_rng(5), B, n)[0]).cuda()
+    a = pipeline.solve_batch(D, guides=("weight",), max_outer_iters=5, chunk=4)
+    b = pipeline.solve_batch(D, guides=("weight",), max_outer_iters=5, chunk=64)
+    assert a.timing["chunks"] == 3 and b.timing["chunks"] == 1
+    assert torch.equal(a.best_tour, b.best_tour) and torch.equal(a.best_cost, b.best_cost)
+    with pytest.raises(ValueError):
+        pipeline.solve_batch(D, guides=("regret_pred",))
+    with pytest.raises(ValueError):
+        pipeline.solve_batch(D, guides=("width",))
+
+
+@pytest.mark.parametrize("n,B", [(100, 8), (200, 2)])
+def test_forward_relabelling_equivariance(model, n, B):
+    """Size-independent property of the GNN on the line graph of K_n: relabelling the TSP nodes with a permutation
+    permutes the predicted regret matrix the same way (R'[p[i], p[j]] = R[i, j]); the instances of a batch do not
+    interact (evaluating an instance alone gives the same bits)."""
+    from gnngls_amd import pipeline
+    from gnngls_amd.synthetic import random_instances
+    rng = np.random.default_rng(n)
+    D_host, _ = random_instances(rng, B, n)
+    D = torch.from_numpy(D_host).cuda()
+    sc = pipeline.Scalers.fit_weights(D)
+    R = pipeline.predict_regret(model, D, sc)
+    assert torch.isfinite(R).all() and (R >= 0).all() and torch.equal(R, R.transpose(1, 2))
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    Dp = torch.empty_like(D)
+    Dp[:, perm[:, None], perm[None, :]] = D
+    Rp = pipeline.predict_regret(model, Dp.contiguous(), sc)
+    back = Rp[:, perm[:, None], perm[None, :]]
+    scale = R.abs().max().item()
+    assert (back - R).abs().max().item() <= 2e-5 * scale + 1e-12        # different summation orders, fp32
+    R0 = pipeline.predict_regret(model, D[:1].contiguous(), sc)
+    assert torch.equal(R0[0], R[0])
