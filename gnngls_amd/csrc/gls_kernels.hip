@@ -97,13 +97,17 @@ struct TriStore {
 };
 
 // Compact store: only the fp64 distance triangle is LDS-resident (n=100: 39.6 KB, with byte-sized tour
-// arrays exactly 40 KiB per workgroup -> FOUR resident workgroups per CU); the penalty triangle
-// lives in global memory (int32, L2-resident: 19.8 KB per instance) and is accessed with agent-scope
-// relaxed atomics (sc1 loads / L2 atomic add), which are coherent without any cache maintenance.
+// arrays exactly 40 KiB per workgroup -> FOUR resident workgroups per CU); the penalty triangle lives in
+// global memory as uint16 (9.9 KB per TSP100 instance: the four instances of a CU fit its 32 KB vector L1).
+// It is written only by wavefront 0 of the owning workgroup and read only by that wavefront, with plain
+// loads/stores: in-order within the wave through the CU's write-through L1, so no atomics or cache
+// maintenance are needed and most reads are L1 hits.  A counter that would pass 65535 aborts the instance
+// with GNNGLS_STATUS_PENALTY_OVERFLOW_DEV (the host reruns it on a 32-bit store).
 struct TriDGlobalP {
     const double *d;   // LDS
-    int32_t *p;        // global, packed triangle
-    using pen_t = int32_t;
+    uint16_t *p;       // global, packed triangle
+    int limit;
+    using pen_t = uint16_t;
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
@@ -114,11 +118,12 @@ struct TriDGlobalP {
         return ((hi * (hi - 1)) >> 1) + lo;
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
-    __device__ __forceinline__ int pen(int a, int b) const {
-        return __hip_atomic_load(p + idx(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
-        (void)__hip_atomic_fetch_add(p + idx(a, b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int q = idx(a, b);
+        const int v = (int)p[q];
+        if (v >= limit) return true;
+        p[q] = (uint16_t)(v + 1);
         return false;
     }
 };
@@ -588,7 +593,8 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
             for (int q = tid; q < ntri; q += nthr) ptri[q] = (PT)0;          // algorithms.py:138
             s.p = ptri; s.limit = A.pen16_limit;
         } else {
-            s.p = A.pen_ws + (size_t)b * ntri;                                // zeroed by the host
+            s.p = reinterpret_cast<uint16_t *>(A.pen_ws) + (size_t)b * ((ntri + 1) & ~1);   // zeroed by the host
+            s.limit = A.pen16_limit;
         }
     } else {
         s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host

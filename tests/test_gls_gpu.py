@@ -210,7 +210,8 @@ def test_gls_penalty_width_variants(ops, bits):
     assert np.array_equal(r.penalty[0].cpu().numpy(), g["penalty"])
 
 
-def test_gls_penalty16_overflow_is_detected_and_rerun(ops):
+@pytest.mark.parametrize("bits16", [16, 0])      # 16: uint16 triangle in LDS; 0 (auto at n=100): compact store, uint16 in global
+def test_gls_penalty16_overflow_is_detected_and_rerun(ops, bits16):
     """A 16-bit penalty counter that would overflow stops the instance with status 2; ops.gls_run reruns
     it with 32-bit counters, so the final result equals the 32-bit run (test hook lowers the limit)."""
     from gnngls_amd import _lib
@@ -222,9 +223,9 @@ def test_gls_penalty16_overflow_is_detected_and_rerun(ops):
     L = _lib.load()
     _lib.check(L.gnngls_debug_set_penalty16_limit(2))
     try:
-        raw = ops.gls_run(*args, penalty_bits=16, retry_overflow=False, **kw)
+        raw = ops.gls_run(*args, penalty_bits=bits16, retry_overflow=False, **kw)
         assert int(raw.status[0]) == ops.STATUS_PENALTY_OVERFLOW
-        r = ops.gls_run(*args, penalty_bits=16, **kw)
+        r = ops.gls_run(*args, penalty_bits=bits16, **kw)
     finally:
         _lib.check(L.gnngls_debug_set_penalty16_limit(65535))
     assert int(r.status[0]) == 0
