@@ -86,6 +86,8 @@ struct TriStore {
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
+    __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
+    __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     int limit;         // largest representable count (65535 for 16-bit counters; lowered only by the test hook)
     __device__ __forceinline__ bool pen_inc(int a, int b) const {     // true = counter overflow
         const int q = idx(a, b);
@@ -119,6 +121,8 @@ struct TriDGlobalP {
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
+    __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
+    __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
         const int q = idx(a, b);
         const int v = (int)p[q];
@@ -135,8 +139,11 @@ struct GlobalStore {
     int32_t *p;
     int n;
     static constexpr bool kSymmetric = false;
+    __device__ __forceinline__ int idx(int a, int b) const { return a * n + b; }
     __device__ __forceinline__ double dist(int a, int b) const { return d[(size_t)a * n + b]; }
     __device__ __forceinline__ int pen(int a, int b) const { return p[(size_t)a * n + b]; }
+    __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
+    __device__ __forceinline__ int pen_at(int q) const { return p[q]; }
     using pen_t = int32_t;
     using tour_t = int32_t;
     static constexpr bool kPenInLds = false;
@@ -469,6 +476,58 @@ __device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n
     }
 }
 
+// Guided one-to-all scans of the perturbation phase (algorithms.py:171-174 on edge_weight + k*penalties).
+// Same arithmetic as two_opt_cost / relocate_cost with GuidedDist, but all penalty and distance loads of an
+// evaluation are issued back to back BEFORE any arithmetic: written through the generic functor the compiler
+// (scheduling for minimum register pressure) emits load -> wait -> use six times in a row, and each wait is a
+// full L1/L2 (penalties) or LDS (distances) round trip on the serial chain of the search.
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_two_opt_o2a_guided(const S &s, double k, const TT *t, int n, int i,
+                                                        int lane, double &bd, int &bk) {
+    for (int j = 1 + lane; j <= n - 1; j += kWave) {
+        int dj = i - j; if (dj < 0) dj = -dj;
+        if (dj < 2) continue;                                // operators.py:61-62
+        const int ii = i < j ? i : j, jj = i < j ? j : i;    // operators.py:17-18
+        const int a = t[ii], b = t[ii - 1], c = t[jj], d = t[jj - 1];
+        const int q0 = s.idx(a, c), q1 = s.idx(b, d), q2 = s.idx(a, b), q3 = s.idx(c, d);
+        const int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2), p3 = s.pen_at(q3);
+        const double d0 = s.dist_at(q0), d1 = s.dist_at(q1), d2 = s.dist_at(q2), d3 = s.dist_at(q3);
+        const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
+        const double g2 = d2 + k * (double)p2, g3 = d3 + k * (double)p3;
+        double delta = g0 + g1;                              // operators.py:25-28, left to right
+        delta = delta - g2;
+        delta = delta - g3;
+        consider<FI>(delta, j, bd, bk);
+    }
+}
+
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, const TT *t, int n, int i,
+                                                         int lane, double &bd, int &bk) {
+    const int a = t[i - 1], b = t[i], c = t[i + 1];
+    const int qab = s.idx(a, b), qbc = s.idx(b, c), qac = s.idx(a, c);
+    const int pab = s.pen_at(qab), pbc = s.pen_at(qbc), pac = s.pen_at(qac);
+    const double gab = s.dist_at(qab) + k * (double)pab;
+    const double gbc = s.dist_at(qbc) + k * (double)pbc;
+    const double gac = s.dist_at(qac) + k * (double)pac;
+    double base = -gab;                                      // operators.py:97-99, left to right
+    base = base - gbc;
+    base = base + gac;
+    for (int j = 1 + lane; j <= n - 1; j += kWave) {
+        if (j == i) continue;                                // operators.py:114-115
+        int d, e;
+        if (i < j) { d = t[j]; e = t[j + 1]; } else { d = t[j - 1]; e = t[j]; }
+        const int q0 = s.idx(d, e), q1 = s.idx(d, b), q2 = s.idx(b, e);
+        const int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2);
+        const double d0 = s.dist_at(q0), d1 = s.dist_at(q1), d2 = s.dist_at(q2);
+        const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1, g2 = d2 + k * (double)p2;
+        double delta = base - g0;                            // operators.py:100-102
+        delta = delta + g1;
+        delta = delta + g2;
+        consider<FI>(delta, j, bd, bk);
+    }
+}
+
 // new tour + edge arrays in one pass; caller synchronises afterwards.
 template <class S, class TT>
 __device__ __forceinline__ void apply_move(const S &s, const TT *told, TT *tnew, double *Ef, double *Eb,
@@ -709,8 +768,8 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
 #pragma unroll 1
                     for (int op = 0; op < 2; ++op) {                           // algorithms.py:171
                         double bd = 0.0; int bk = kNoKey;
-                        if (op == 0) scan_two_opt_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
-                        else         scan_relocate_o2a<GuidedDist<S>, FI>(t, gd, n, i, lane, kWave, bd, bk);
+                        if (op == 0) scan_two_opt_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk);
+                        else         scan_relocate_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk);
                         // most one-to-all scans find no improving move: one ballot decides whether the
                         // three-stage arg-min is needed at all
                         STAMP_END(1);   // penalty update + position search + o2a scan
