@@ -170,10 +170,9 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (cfg.store != gnngls::GLS_STORE_TRI) {
         // penalties in global memory (zeroed workspace): full matrices for the global store, packed
         // triangles for the compact store
-        // global store: int32 [n,n] per instance; compact store: uint16 packed triangle (padded to an even count)
-        size_t bytes = cfg.store == gnngls::GLS_STORE_GLOBAL
-                           ? (size_t)B * n * n * sizeof(int32_t)
-                           : (size_t)B * ((((size_t)n * (n - 1) / 2) + 1) & ~size_t(1)) * sizeof(uint16_t);
+        // global store: int32 [n,n] per instance; compact store: int32 packed triangle
+        size_t per = cfg.store == gnngls::GLS_STORE_GLOBAL ? (size_t)n * n : (size_t)n * (n - 1) / 2;
+        size_t bytes = (size_t)B * per * sizeof(int32_t);
         hipError_t e = hipMallocAsync((void **)&ws, bytes, st);
         if (e != hipSuccess) return hip_fail(e, "gls_run: workspace alloc");
         e = hipMemsetAsync(ws, 0, bytes, st);

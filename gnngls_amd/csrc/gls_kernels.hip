@@ -100,16 +100,15 @@ struct TriStore {
 
 // Compact store: only the fp64 distance triangle is LDS-resident (n=100: 39.6 KB, with byte-sized tour
 // arrays exactly 40 KiB per workgroup -> FOUR resident workgroups per CU); the penalty triangle lives in
-// global memory as uint16 (9.9 KB per TSP100 instance: the four instances of a CU fit its 32 KB vector L1).
-// It is written only by wavefront 0 of the owning workgroup and read only by that wavefront, with plain
-// loads/stores: in-order within the wave through the CU's write-through L1, so no atomics or cache
-// maintenance are needed and most reads are L1 hits.  A counter that would pass 65535 aborts the instance
-// with GNNGLS_STATUS_PENALTY_OVERFLOW_DEV (the host reruns it on a 32-bit store).
+// global memory as int32 (19.8 KB per TSP100 instance, L1/L2-resident).  It is written only by wavefront 0 of
+// the owning workgroup and read only by that wavefront, with plain loads/stores: in-order within the wave
+// through the CU's write-through L1, so no atomics or cache maintenance are needed.  (uint16 counters were
+// 4 % faster but overflow within a 10 s run when an uninformative guide concentrates the penalties on few
+// edges -- 800k penalty steps per instance -- and an overflow costs a whole rerun.)
 struct TriDGlobalP {
     const double *d;   // LDS
-    uint16_t *p;       // global, packed triangle
-    int limit;
-    using pen_t = uint16_t;
+    int32_t *p;        // global, packed triangle
+    using pen_t = int32_t;
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
@@ -124,10 +123,7 @@ struct TriDGlobalP {
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
-        const int q = idx(a, b);
-        const int v = (int)p[q];
-        if (v >= limit) return true;
-        p[q] = (uint16_t)(v + 1);
+        p[idx(a, b)] += 1;
         return false;
     }
 };
@@ -652,8 +648,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
             for (int q = tid; q < ntri; q += nthr) ptri[q] = (PT)0;          // algorithms.py:138
             s.p = ptri; s.limit = A.pen16_limit;
         } else {
-            s.p = reinterpret_cast<uint16_t *>(A.pen_ws) + (size_t)b * ((ntri + 1) & ~1);   // zeroed by the host
-            s.limit = A.pen16_limit;
+            s.p = A.pen_ws + (size_t)b * ntri;                                // zeroed by the host
         }
     } else {
         s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host
