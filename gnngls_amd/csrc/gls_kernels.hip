@@ -158,17 +158,6 @@ struct PlainDist {
     __device__ __forceinline__ double operator()(int a, int b) const { return s.dist(a, b); }
 };
 
-// [exact] edge_weight + k * edge_penalties (algorithms.py:164): product rounded, then sum rounded.
-template <class S>
-struct GuidedDist {
-    const S &s;
-    double k;
-    __device__ __forceinline__ double operator()(int a, int b) const {
-        double kp = k * (double)s.pen(a, b);
-        return s.dist(a, b) + kp;
-    }
-};
-
 // ---------------------------------------------------------------------------------------------
 // Move evaluation, reference operand order   [exact]
 // ---------------------------------------------------------------------------------------------
@@ -680,7 +669,6 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     __syncthreads();
 
     long long iter_i = 0;
-    const GuidedDist<S> gd{s, k};
 
     for (;;) {
         // ---- loop condition (algorithms.py:146) ----
