@@ -31,6 +31,7 @@ SIGNATURES = {
     "gnngls_pack_features": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_debug_set_penalty16_limit": [_int],
+    "gnngls_debug_set_stamp_buffer": [_vp],
     "gnngls_profile_enable": [_int],
     "gnngls_profile_collect": [_vp, _vp],
 }

@@ -47,6 +47,7 @@ struct ProfScope {
 };
 
 int g_pen16_limit = 65535;
+long long *g_stamp_buffer = nullptr;
 
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr int kMaxWavesPerCU = 32;
@@ -164,6 +165,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.best_tour = best_tour; A.best_cost = best_cost; A.outer_iters = (long long *)outer_iters;
     A.trace_cost = trace_cost; A.trace_time = trace_time; A.trace_cap = trace_cost ? trace_cap : 0;
     A.pen16_limit = g_pen16_limit;
+    A.stamps = g_stamp_buffer;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
     const GlsConfig cfg = gls_config(n, penalty_bits);
     int32_t *ws = nullptr;
@@ -290,6 +292,11 @@ extern "C" {
 int gnngls_debug_set_penalty16_limit(int limit) {
     if (limit < 1 || limit > 65535) return fail(GNNGLS_ERR_ARG, "penalty16 limit must be in 1..65535");
     g_pen16_limit = limit;
+    return GNNGLS_OK;
+}
+
+int gnngls_debug_set_stamp_buffer(void *device_buffer) {
+    g_stamp_buffer = (long long *)device_buffer;
     return GNNGLS_OK;
 }
 

@@ -29,6 +29,7 @@ struct GlsArgs {
     int32_t *status;
     int32_t *pen_ws;           // global store: [B,n,n] int32; compact store: [B,n(n-1)/2] int32; zeroed by the host
     int pen16_limit;           // 65535 (see gnngls_debug_set_penalty16_limit)
+    long long *stamps;         // diagnostic builds (-DGLS_STAMPS) only: [B,8] cycle totals, else unused
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };

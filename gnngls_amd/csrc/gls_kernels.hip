@@ -821,7 +821,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (A.evals) A.evals[b] = evals;
         if (A.status) A.status[b] = status;
 #ifdef GLS_STAMPS
-        if (A.outer_iters) { long long *o = reinterpret_cast<long long *>(A.outer_iters) + (size_t)A.B + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
+        if (A.stamps) { long long *o = A.stamps + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
 #endif
     }
     if (A.penalty_out) {

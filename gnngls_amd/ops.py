@@ -6,7 +6,6 @@ The reference-signature mirrors (operators.py / algorithms.py of this package) a
 list-in/list-out wrappers over these.
 """
 import ctypes
-import os
 from dataclasses import dataclass
 
 import torch
@@ -126,7 +125,7 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 120.0
     best_tour = torch.empty_like(init_tour)
     best_cost = torch.empty((B,), dtype=torch.float64, device=dev)
-    outer = torch.zeros((B * (9 if os.environ.get('GNNGLS_STAMPS') else 1),), dtype=torch.int64, device=dev)
+    outer = torch.zeros((B,), dtype=torch.int64, device=dev)
     trace_cost = torch.zeros((B, trace_cap), dtype=torch.float64, device=dev) if trace_cap > 0 else None
     trace_time = torch.zeros((B, trace_cap), dtype=torch.float32, device=dev) if (trace_cap > 0 and want_trace_time) else None
     trace_len = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -141,10 +140,7 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         _lib.ptr(best_tour), _lib.ptr(best_cost), _lib.ptr(outer),
         _lib.ptr(trace_cost), _lib.ptr(trace_time), int(trace_cap), _lib.ptr(trace_len),
         _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status), _lib.current_stream()), "gls_run")
-    stamps = outer[B:].reshape(B, 8) if outer.numel() > B else None
-    outer = outer[:B]
     res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
-    res.stamps = stamps
     if retry_overflow and penalty_bits != 32:
         bad = (status == STATUS_PENALTY_OVERFLOW).nonzero().flatten()
         if bad.numel() > 0:

@@ -145,6 +145,10 @@ int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_
  * the overflow -> rerun-with-32-bit path can be exercised in seconds.  Never called by the product. */
 int gnngls_debug_set_penalty16_limit(int limit);
 
+/* Diagnostic hook: device buffer of 8 int64 per instance that a library built with -DGLS_STAMPS fills with
+ * per-phase shader-cycle totals of gnngls_gls_run (scripts/probe_gls_stamps.py).  Ignored by normal builds. */
+int gnngls_debug_set_stamp_buffer(void *device_buffer);
+
 /* ---- measurement hooks (bench.py): per-kernel-class device time via HIP events recorded on the
  * caller's stream around every launch made while profiling is enabled.  gnngls_profile_collect
  * synchronises the recorded events, sums milliseconds and launch counts per class (arrays of

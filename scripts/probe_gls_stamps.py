@@ -7,18 +7,21 @@ sys.path.insert(0, ".")
 from gnngls_amd import ops
 from gnngls_amd.synthetic import random_instances
 import os
-os.environ['GNNGLS_STAMPS'] = '1'
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()
 init = ops.nearest_neighbor(D); cost = ops.tour_cost(init, D)
-# GNNGLS_STAMPS=1 makes ops.gls_run allocate 8 extra int64 per instance behind outer_iters (the stamp sink);
+# the stamp sink is a side buffer registered through the debug hook of the C ABI;
 # trace_cap=0 = the throughput path (trace-free kernel instantiation, deferred tour_cost)
+from gnngls_amd import _lib
+stamps = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
+_lib.check(_lib.load().gnngls_debug_set_stamp_buffer(_lib.ptr(stamps)))
 tc = int(os.environ.get("TRACE_CAP", "0"))
 r = ops.gls_run(D, D[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
 torch.cuda.synchronize()
-st = r.stamps.double().mean(0).cpu().numpy()
+st = stamps.double().mean(0).cpu().numpy()
+assert st.sum() > 0, 'library was not built with GNNGLS_EXTRA_FLAGS=-DGLS_STAMPS'
 names = ["utility argmax", "o2a scan (+pen, pos search)", "o2a reduce", "apply+reload", "phase tail", "descent (LS)", "steps"]
 tot = st[:6].sum()
 it = r.outer_iters.double().mean().item()
