@@ -84,6 +84,10 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
     cap = ops.gls_resident_capacity(n)
     if chunk is None:
         chunk = cap if cap > 0 else 64
+        # equal-sized rounds: a batch a little larger than the device capacity is split evenly (same number of
+        # rounds, i.e. the same wall time, but every round leaves the SIMDs less crowded)
+        rounds = -(-B // chunk)
+        chunk = -(-B // rounds) if B > 0 else chunk
     outs, timing = [], {"forward_s": 0.0, "init_s": 0.0, "search_s": 0.0, "chunks": 0}
     for b0 in range(0, B, chunk):
         Dc = D[b0:b0 + chunk].contiguous()
