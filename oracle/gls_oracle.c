@@ -247,7 +247,6 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     double *pen = (double *)calloc(nn, sizeof(double));          /* :138 */
     double *Dg = (double *)malloc(nn * sizeof(double));
     int32_t *cur = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
-    int32_t *cand = (int32_t *)malloc((size_t)(n + 1) * sizeof(int32_t));
     trace_t tr = { trace_cost, trace_cap, 0 };
     int64_t evals = 0;
 
@@ -312,7 +311,7 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     if (trace_len) *trace_len = tr.len;
     if (outer_iters_out) *outer_iters_out = iter_i;
     if (evals_out) *evals_out = evals;
-    free(pen); free(Dg); free(cur); free(cand);
+    free(pen); free(Dg); free(cur);
     return best_cost;
 }
 
