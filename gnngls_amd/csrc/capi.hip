@@ -65,11 +65,15 @@ int num_cus() {
 // most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
 struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; };
 
-GlsConfig gls_config(int n, int requested_bits) {
+GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
     GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, gnngls::gls_block_threads(n, gnngls::GLS_STORE_GLOBAL),
                    gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0};
-    bool have = false;
+    bool have = false, done = false;
+    const int cus = num_cus();
+    // candidates are visited fastest store first (LDS penalties 32-bit, LDS penalties 16-bit, compact); the first one
+    // that keeps the whole batch resident wins, otherwise the one with the most resident workgroups per CU
     auto consider = [&](int store, int bits) {
+        if (done) return;
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
         const int threads = gnngls::gls_block_threads(n, store);
@@ -79,9 +83,12 @@ GlsConfig gls_config(int n, int requested_bits) {
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;
         if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }
+        if (batch > 0 && (long)per_cu * cus >= batch) { pick = GlsConfig{store, bits, threads, lds, per_cu}; done = true; }
     };
     if (requested_bits == 0 || requested_bits == 32) consider(gnngls::GLS_STORE_TRI, 32);
-    if (requested_bits == 0 || requested_bits == 16) consider(gnngls::GLS_STORE_TRI, 16);
+    // 16-bit LDS counters only on request: they overflow within a 10 s run when an uninformative guide
+    // concentrates the penalties on a few edges, and an overflow costs a whole rerun of that instance
+    if (requested_bits == 16) consider(gnngls::GLS_STORE_TRI, 16);
     if (requested_bits == 0 && n <= 255) consider(gnngls::GLS_STORE_COMPACT, 32);
     return pick;
 }
@@ -167,7 +174,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.pen16_limit = g_pen16_limit;
     A.stamps = g_stamp_buffer;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
-    const GlsConfig cfg = gls_config(n, penalty_bits);
+    const GlsConfig cfg = gls_config(n, penalty_bits, B);
     int32_t *ws = nullptr;
     if (cfg.store != gnngls::GLS_STORE_TRI) {
         // penalties in global memory (zeroed workspace): full matrices for the global store, packed

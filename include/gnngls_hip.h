@@ -86,9 +86,10 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  *   max_outer_iters <  0 : run until time_limit_s seconds of device wall clock have elapsed since
  *                          the workgroup started (reference mode, `while time.time() < t_lim`)
  *   penalty_bits width of the LDS-resident penalty counters (algorithms.py:138,161): 32, 16, or
- *                0 = auto (16 only where it buys one more resident workgroup per CU, e.g. n=100:
- *                3 instead of 2).  A 16-bit counter about to overflow stops that instance with
- *                GNNGLS_STATUS_PENALTY_OVERFLOW; the caller reruns it with penalty_bits=32.
+ *                0 = auto: the fastest store that keeps all B instances resident (32-bit LDS counters, then the
+ *                compact store with 32-bit counters in global memory), else the one with the largest
+ *                residency.  16 = uint16 LDS counters (n=100: 3 workgroups per CU): a counter about to
+ *                overflow stops that instance with GNNGLS_STATUS_PENALTY_OVERFLOW; the caller reruns it with 32.
  *   watchdog_s   hard abort (status GNNGLS_STATUS_WATCHDOG) if a workgroup runs longer than this
  *   outputs      best_tour [B,n+1], best_cost [B], outer_iters [B] (int64),
  *                trace_cost [B,trace_cap] cost after every accepted move (algorithms.py:127-130,
