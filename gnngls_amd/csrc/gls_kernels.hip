@@ -8,17 +8,21 @@
 //
 // Design (MI355X-first):
 //   * one persistent workgroup per TSP instance; the instance never leaves the CU: the fp64
-//     distance matrix and the int32 penalty matrix live in LDS as packed lower triangles
-//     (n=100: 39.6 KB + 19.8 KB), the tour is ping-ponged between two LDS arrays, and there is no
-//     host round trip per move;
+//     distance matrix lives in LDS as a packed lower triangle (n=100: 39.6 KB), the tour is
+//     ping-ponged between two LDS arrays, and there is no host round trip per move.  Where the
+//     penalty counters live is a storage policy (TriStore: LDS triangle, 2-3 workgroups per CU;
+//     TriDGlobalP: global memory behind the L1, exactly 40 KiB of LDS -> 4 workgroups per CU =
+//     1024 resident TSP100 instances; GlobalStore: everything in HBM/L2 for any n);
 //   * an a2a scan gives one tour row (fixed i) to a wavefront and the j axis to its 64 lanes, so
 //     t[i], t[i-1] and the row constants are wave-uniform, tour reads are conflict-free and each
 //     evaluation costs two random LDS reads (the other terms are the per-position edge lengths
 //     Ef[], rebuilt in O(n) after every move);
 //   * best-improvement selection is an arg-min on the key (delta, i, j): identical to the
-//     reference's sequential strict-< scan (first minimum in enumeration order wins);
+//     reference's sequential strict-< scan (first minimum in enumeration order wins); inside a
+//     wavefront it is three 32-bit DPP min-reductions, no LDS-crossbar shuffles;
 //   * the perturbation phase (O(n) work per step, long serial chain) runs in wavefront 0 only, so
-//     it needs no workgroup barriers; the other wavefronts park on one barrier;
+//     it needs no workgroup barriers; the other wavefronts park on one barrier; utilities of the
+//     tour edges are cached in registers, guided evaluations issue all their loads up front;
 //   * all floating point is fp64 with contraction OFF: the guided matrix `D + k*P`
 //     (algorithms.py:164) must round twice, np.isclose (operators.py:42) is evaluated literally.
 //
