@@ -8,6 +8,10 @@ the same DataFrame pickle (columns instance,time,opt_cost,cost,best_cost,gap,dt)
 The per-instance loop of the reference (test.py:59) is replaced by batches on the GPU: every instance
 of a batch gets the full --time_limit concurrently (gnngls_amd.pipeline.solve_batch).  `--use_gpu`
 is accepted for compatibility; this implementation always runs on the GPU and has no CPU path.
+
+Multi-GPU: launched under torchrun (one process per GPU) the instance list is split into contiguous
+blocks (gnngls_amd.parallel.shard_range), every rank searches its block, and the per-instance records
+are gathered once on rank 0, which writes the single DataFrame.
 """
 import argparse
 import datetime
@@ -24,8 +28,12 @@ import tqdm.auto as tqdm
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 
+import os  # noqa: E402
+
+import torch.distributed as dist  # noqa: E402
+
 import gnngls_amd  # noqa: E402
-from gnngls_amd import datasets, models, pipeline  # noqa: E402
+from gnngls_amd import datasets, models, parallel, pipeline  # noqa: E402
 from gnngls_amd.algorithms import _attr_matrix  # noqa: E402
 
 if __name__ == '__main__':
@@ -39,6 +47,11 @@ if __name__ == '__main__':
     parser.add_argument('--use_gpu', action='store_true')
     parser.add_argument('--batch_size', type=int, default=0, help='instances searched concurrently (0 = device capacity)')
     args = parser.parse_args()
+
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
+    if world > 1:
+        dist.init_process_group(os.environ.get('GNNGLS_DIST_BACKEND', 'nccl'))
 
     params = json.load(open(args.model_path.parent / 'params.json'))
     if 'efeat_drop_idx' in params:
@@ -63,9 +76,11 @@ if __name__ == '__main__':
     bs = args.batch_size or max(gnngls_amd.ops.gls_resident_capacity(n), 1)
     gaps = []
     search_progress = []
-    pbar = tqdm.tqdm(total=len(test_set.instances))
-    for b0 in range(0, len(test_set.instances), bs):
-        names = test_set.instances[b0:b0 + bs]
+    lo, hi = parallel.shard_range(len(test_set.instances), world, rank)      # this rank's block of instances
+    my_instances = test_set.instances[lo:hi]
+    pbar = tqdm.tqdm(total=len(my_instances), disable=rank != 0)
+    for b0 in range(0, len(my_instances), bs):
+        names = my_instances[b0:b0 + bs]
         graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
         opt_costs = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
         D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
@@ -85,6 +100,15 @@ if __name__ == '__main__':
         pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})
         pbar.update(len(names))
     pbar.close()
+
+    if world > 1:                                   # one gather of the per-instance records
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(search_progress, parts, dst=0)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            sys.exit(0)
+        search_progress = [row for part in parts for row in part]
 
     search_progress_df = pd.DataFrame.from_records(search_progress)
     search_progress_df['best_cost'] = search_progress_df.groupby('instance')['cost'].cummin()

@@ -146,6 +146,16 @@ def test_cli_end_to_end(tmp_path):
            str(mdir / "checkpoint_best_val.pt"), str(run_dir), "regret_pred", "weight", "--time_limit", "0.3",
            "--perturbation_moves", "10", "--use_gpu"]
     subprocess.check_call(cmd, cwd=ROOT)
+    # the same run as two instance-sharded ranks (gloo: both ranks share this box's GPU)
+    run_dir2 = tmp_path / "runs2"
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+            "127.0.0.1", "--master-port", "29544"] + cmd[1:]
+    cmd2[cmd2.index(str(run_dir))] = str(run_dir2)
+    subprocess.check_call(cmd2, cwd=ROOT, env=dict(os.environ, GNNGLS_DIST_BACKEND="gloo"))
+    out2 = list(run_dir2.glob("*.pkl"))
+    assert len(out2) == 1
+    df2 = pickle.load(open(out2[0], "rb"))
+    assert sorted(df2["instance"].unique()) == names and (df2.groupby("instance")["gap"].last() < 0).all()
     out = list(run_dir.glob("*.pkl"))
     assert len(out) == 1
     df = pickle.load(open(out[0], "rb"))
