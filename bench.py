@@ -115,7 +115,11 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm):
             "sample": f"{cores} TSP{D.shape[1]} instances of the same batch, one per host core, {time_limit:g} s "
                       f"search budget each (GNN forward not charged to the CPU), guides as on the GPU",
             "mean_gap_pct": float(gaps.mean()), "outer_iters_per_instance": float(np.mean([o["outer_iters"] for o in outs])),
-            "delta_evals_per_s": float(sum(o["evals"] for o in outs) / wall), "wall_s": wall}
+            "delta_evals_per_s": float(sum(o["evals"] for o in outs) / wall), "wall_s": wall,
+            # context, NOT measured on this box: the reference's own Python on one core of the build container
+            # (SURVEY.md section 6 / BASELINE.md section 2, TSP100): the C port above is ~1400x faster per core
+            "reference_python_probe": {"outer_iters_per_instance_10s": 41, "delta_evals_per_s": 5.1e5,
+                                       "instances_per_s_per_core": 0.1, "source": "BASELINE.md section 2"}}
 
 
 def main():
