@@ -952,7 +952,8 @@ int gls_block_threads(int n, int store) {
     // compact store, 4 workgroups per CU, measured at TSP100 x 1024 (outer iterations per instance in 2 s):
     //   8 waves, 64 VGPRs (32 B of scratch in the serial phase)            7.9k   <- used
     //   4 waves, 128 VGPRs, no spills, descent scans batched 4-deep for ILP  7.4k
-    //   6 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (3 resident only)
+    //   6 or 7 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (3 resident only)
+    //   5 waves at <= 80 VGPRs (no spills) pack and reach 9.6k vs 9.9k for 8 waves; at 85+ VGPRs they no longer pack
     return 512;
 }
 
