@@ -18,6 +18,7 @@ SIGNATURES = {
     "gnngls_abi_version": [],
     "gnngls_last_error": [],
     "gnngls_gls_resident_capacity": [_int],
+    "gnngls_gls_describe_config": [_int, _int, _int, _vp, _vp, _vp, _vp],
     "gnngls_two_opt_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_relocate_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_best_move": [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp],

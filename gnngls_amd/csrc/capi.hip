@@ -106,6 +106,17 @@ int gnngls_gls_resident_capacity(int n) {
     return c.per_cu * num_cus();
 }
 
+int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu) {
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32))
+        return fail(GNNGLS_ERR_ARG, "gls_describe_config: bad argument");
+    const GlsConfig c = gls_config(n, penalty_bits, B);
+    if (store) *store = c.store * 100 + (c.store == gnngls::GLS_STORE_TRI ? c.penalty_bits : 0);
+    if (threads) *threads = c.threads;
+    if (lds_bytes) *lds_bytes = (int)c.lds;
+    if (per_cu) *per_cu = c.store == gnngls::GLS_STORE_GLOBAL ? 0 : c.per_cu;
+    return GNNGLS_OK;
+}
+
 int gnngls_two_opt_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream) {
     if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!tour || !D || !out || B < 0 || n < 3) return fail(GNNGLS_ERR_ARG, "two_opt_delta_all: bad argument");

@@ -158,3 +158,13 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
 
 def gls_resident_capacity(n):
     return _lib.load().gnngls_gls_resident_capacity(int(n))
+
+
+def gls_describe_config(n, B=0, penalty_bits=0):
+    """-> dict(store, threads, lds_bytes, per_cu): what gnngls_gls_run would use (host-side query)."""
+    vals = [ctypes.c_int(0) for _ in range(4)]
+    _lib.check(_lib.load().gnngls_gls_describe_config(int(n), int(B), int(penalty_bits),
+                                                      *[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals]),
+               "gls_describe_config")
+    names = {0: "global", 116: "lds-tri-u16", 132: "lds-tri-i32", 200: "compact"}
+    return {"store": names[vals[0].value], "threads": vals[1].value, "lds_bytes": vals[2].value, "per_cu": vals[3].value}

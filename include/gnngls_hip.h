@@ -49,6 +49,12 @@ const char *gnngls_last_error(void);
  * global-memory fallback.  Host-side query, no device work. */
 int gnngls_gls_resident_capacity(int n);
 
+/* Host-side query: the storage configuration gnngls_gls_run would use for B instances of n nodes.
+ *   *store     0 = global-memory store, 116 / 132 = distance + 16/32-bit penalty triangles in LDS,
+ *              200 = compact store (distance triangle in LDS, penalties in global memory)
+ *   *threads   workgroup size, *lds_bytes dynamic LDS per workgroup, *per_cu resident workgroups per CU (0: n/a) */
+int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu);
+
 /* ---- K3u: move-evaluation tables (parity/unit kernels) ---------------------------------------
  * out[b][i][j] (shape [B, n+1, n+1]) = two_opt_cost(tour_b, D_b, i, j)   operators.py:14-29
  *                                    = relocate_cost(tour_b, D_b, i, j)  operators.py:83-103

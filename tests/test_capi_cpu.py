@@ -65,3 +65,16 @@ def test_no_cpu_fallback_without_gpu():
     m = EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8).eval()
     with pytest.raises(_lib.GnnglsHipError):
         m(LineGraph(4), torch.zeros(6, 1))
+
+
+def test_gls_store_selection(lib):
+    """Fastest store that keeps the batch resident; the compact store is exactly 40 KiB at n=100 (4 per CU)."""
+    from gnngls_amd import ops
+    c = ops.gls_describe_config(100, 1024)
+    assert c == {"store": "compact", "threads": 512, "lds_bytes": 40960, "per_cu": 4}
+    assert ops.gls_describe_config(100, 512)["store"] == "lds-tri-i32" and ops.gls_describe_config(100, 512)["per_cu"] == 2
+    assert ops.gls_describe_config(100, 513)["store"] == "compact"            # 16-bit LDS counters only on request
+    assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3}
+    assert ops.gls_describe_config(200, 256)["store"] == "compact" and ops.gls_describe_config(200, 256)["per_cu"] == 1
+    assert ops.gls_describe_config(300, 8)["store"] == "global"
+    assert 4 * ops.gls_describe_config(100, 1024)["lds_bytes"] == 160 * 1024
