@@ -1,0 +1,94 @@
+"""Randomised parity campaign of the search kernel against the CPU oracle: many sizes, integer-lattice distance
+matrices (exact ties, deltas that are exactly 0 or ~1e-8), zero-heavy guides, all storage policies, both
+improvement modes.  Every accepted move, the best tour and the final penalties must match bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(rng, n, kind):
+    if kind == "euclid":
+        pos = rng.random((n, 2))
+        D = np.sqrt(((pos[:, None] - pos[None]) ** 2).sum(-1))
+    elif kind == "lattice":                       # many exact ties and zero deltas
+        pos = rng.integers(0, 6, size=(n, 2)).astype(np.float64)
+        D = np.abs(pos[:, None] - pos[None]).sum(-1) + 1.0
+    else:                                         # lattice + noise around np.isclose's 1e-8 threshold
+        pos = rng.integers(0, 4, size=(n, 2)).astype(np.float64)
+        D = np.abs(pos[:, None] - pos[None]).sum(-1) + 1.0
+        D = D + rng.choice([0.0, 5e-9, 1e-8, 1.00001e-8, 2e-8, -5e-9, -1e-8], size=D.shape)
+    D = np.triu(D, 1)
+    D = D + D.T
+    g = np.maximum(rng.normal(0.0, 0.1, size=(n, n)).astype(np.float32).astype(np.float64), 0)   # ~half zeros
+    g = np.triu(g, 1)
+    return D, g + g.T
+
+
+CASES = []
+_rng = np.random.default_rng(987654)
+for _ in range(48):
+    CASES.append(dict(n=int(_rng.integers(4, 131)), kind=str(_rng.choice(["euclid", "lattice", "noisy"])),
+                      pm=int(_rng.choice([1, 5, 20, 30])), fi=bool(_rng.integers(0, 2)), K=int(_rng.integers(1, 5)),
+                      bits=int(_rng.choice([0, 16, 32])), guides=int(_rng.integers(1, 3)), seed=int(_rng.integers(1 << 30))))
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: f"n{c['n']}-{c['kind']}-pm{c['pm']}-fi{int(c['fi'])}-K{c['K']}-b{c['bits']}-g{c['guides']}")
+def test_fuzz_case(c):
+    from gnngls_amd import ops
+    from oracle import gls_oracle as go
+    rng = np.random.default_rng(c["seed"])
+    n, B = c["n"], 3
+    Ds, Gs = zip(*[make_case(rng, n, c["kind"]) for _ in range(B)])
+    D = np.stack(Ds)
+    guides = np.stack([np.stack(Gs), D][:c["guides"]])            # [G,B,n,n]: regret-like guide, then 'weight'
+    d = torch.from_numpy(D).cuda()
+    gd = torch.from_numpy(np.ascontiguousarray(guides)).cuda()
+    init = ops.nearest_neighbor(gd[0].contiguous())
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
+                    trace_cap=1 << 13, want_penalty=True, penalty_bits=c["bits"])
+    init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
+    for b in range(B):
+        assert init_h[b].tolist() == go.nearest_neighbor(guides[0, b])
+        o = go.guided_local_search(D[b], guides[:, b], init_h[b], cost_h[b], perturbation_moves=c["pm"],
+                                   first_improvement=c["fi"], max_outer_iters=c["K"])
+        L = o["trace_len"]
+        assert int(r.status[b]) == 0 and int(r.trace_len[b]) == L
+        got = r.trace_cost[b, :L].cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), o["trace"].view(np.uint64)), \
+            f"first mismatch at move {int(np.argmax(got.view(np.uint64) != o['trace'].view(np.uint64)))} of {L}"
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert np.float64(r.best_cost[b].item()).tobytes() == np.float64(o["best_cost"]).tobytes()
+        assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"])
+
+
+@pytest.mark.parametrize("n", [5, 17, 64, 101])
+def test_operators_accept_asymmetric_matrices(n):
+    """The operator-level entry points keep the reference's exact index order (D[a,c], D[b,d], D[a,b], D[c,d] ...),
+    so an asymmetric matrix gives the reference's result too (the LDS-resident search kernel assumes symmetry)."""
+    from gnngls_amd import ops
+    from oracle import gls_oracle as go
+    rng = np.random.default_rng(n)
+    D = rng.random((n, n))
+    np.fill_diagonal(D, 0.0)
+    assert not np.array_equal(D, D.T)
+    tour = np.concatenate([[0], 1 + rng.permutation(n - 1), [0]]).astype(np.int32)
+    t = torch.from_numpy(tour[None]).cuda()
+    d = torch.from_numpy(D[None]).cuda()
+    a, b = ops.two_opt_delta_all(t, d)[0].cpu().numpy(), go.two_opt_delta_all(tour, D)
+    m = ~np.isnan(b)
+    assert np.array_equal(a[m].view(np.uint64), b[m].view(np.uint64))
+    a, b = ops.relocate_delta_all(t, d)[0].cpu().numpy(), go.relocate_delta_all(tour, D)
+    assert np.array_equal(a[m].view(np.uint64), b[m].view(np.uint64))
+    for op, name in ((0, "two_opt"), (1, "relocate")):
+        for fi in (False, True):
+            delta, move, nt = ops.best_move(t, d, op, None, fi)
+            od, ot, _ = getattr(go, name + "_a2a")(tour, D, fi)
+            assert np.float64(delta.item()).tobytes() == np.float64(od).tobytes() and nt[0].cpu().tolist() == ot
+            pos = torch.tensor([n // 2], dtype=torch.int32, device="cuda")
+            delta, move, nt = ops.best_move(t, d, op, pos, fi)
+            od, ot, _ = getattr(go, name + "_o2a")(tour, D, n // 2, fi)
+            assert np.float64(delta.item()).tobytes() == np.float64(od).tobytes() and nt[0].cpu().tolist() == ot
+    assert np.float64(ops.tour_cost(t, d).item()).tobytes() == np.float64(go.tour_cost(tour, D)).tobytes()
