@@ -43,13 +43,17 @@ def local_search(init_tour, init_cost, D, first_improvement=False):
     """algorithms.py:111-132 -> (cur_tour, cur_cost, search_progress)."""
     D = np.asarray(D, dtype=np.float64)
     if not np.array_equal(D, D.T):
-        raise NotImplementedError("the LDS-resident search kernel needs a symmetric distance matrix "
+        # two_opt_cost assumes D[x,y] == D[y,x] (a reversal flips every inner edge), so on an asymmetric matrix the
+        # reference's descent is not a descent at all and need not terminate; refuse instead of spinning
+        raise NotImplementedError("local_search needs a symmetric distance matrix "
                                   "(nx.attr_matrix of an undirected graph always is)")
+    bits = 0
     t0 = time.time()
     r = ops.gls_run(ops.as_dev(D[None], torch.float64), None,
                     ops.as_dev(np.asarray(init_tour, dtype=np.int32)[None], torch.int32),
                     ops.as_dev(np.asarray([init_cost], dtype=np.float64), torch.float64),
-                    first_improvement=first_improvement, max_outer_iters=0, trace_cap=TRACE_CAP, want_trace_time=True)
+                    first_improvement=first_improvement, max_outer_iters=0, trace_cap=TRACE_CAP, want_trace_time=True,
+                    penalty_bits=bits)
     return r.best_tour[0].tolist(), r.best_cost[0].item(), _progress(r, t0)
 
 

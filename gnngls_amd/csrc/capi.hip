@@ -85,6 +85,7 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
         if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }
         if (batch > 0 && (long)per_cu * cus >= batch) { pick = GlsConfig{store, bits, threads, lds, per_cu}; done = true; }
     };
+    if (requested_bits < 0) return pick;      // forced global-memory store (exact index order, asymmetric D allowed)
     if (requested_bits == 0 || requested_bits == 32) consider(gnngls::GLS_STORE_TRI, 32);
     // 16-bit LDS counters only on request: they overflow within a 10 s run when an uninformative guide
     // concentrates the penalties on a few edges, and an overflow costs a whole rerun of that instance
@@ -107,7 +108,7 @@ int gnngls_gls_resident_capacity(int n) {
 }
 
 int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu) {
-    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32))
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1))
         return fail(GNNGLS_ERR_ARG, "gls_describe_config: bad argument");
     const GlsConfig c = gls_config(n, penalty_bits, B);
     if (store) *store = c.store * 100 + (c.store == gnngls::GLS_STORE_TRI ? c.penalty_bits : 0);
@@ -171,8 +172,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (max_outer_iters != 0 && (!guides || n_guides < 1))
         return fail(GNNGLS_ERR_ARG, "gls_run: guides required when outer iterations are requested");
     if (!(watchdog_s > 0.0)) return fail(GNNGLS_ERR_ARG, "gls_run: watchdog_s must be > 0");
-    if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32)
-        return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16 or 32");
+    if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1)
+        return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16, 32 or -1 (global-memory store)");
     hipStream_t st = (hipStream_t)stream;
     gnngls::GlsArgs A;
     memset(&A, 0, sizeof(A));

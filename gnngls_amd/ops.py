@@ -141,7 +141,7 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         _lib.ptr(trace_cost), _lib.ptr(trace_time), int(trace_cap), _lib.ptr(trace_len),
         _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status), _lib.current_stream()), "gls_run")
     res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
-    if retry_overflow and penalty_bits != 32:
+    if retry_overflow and penalty_bits in (0, 16):
         bad = (status == STATUS_PENALTY_OVERFLOW).nonzero().flatten()
         if bad.numel() > 0:
             sub = gls_run(D[bad].contiguous(), None if guides is None else guides[:, bad].contiguous(),

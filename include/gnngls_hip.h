@@ -83,7 +83,8 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
 
 /* ---- K3: guided_local_search (algorithms.py:135-195), local_search (algorithms.py:111-132) -----
  * One persistent workgroup per instance.
- *   D            [B,n,n] fp64, symmetric (it comes from nx.attr_matrix of an undirected graph)
+ *   D            [B,n,n] fp64, symmetric (it comes from nx.attr_matrix of an undirected graph) unless
+ *                penalty_bits == -1
  *   guides       [n_guides,B,n,n] fp64 utility numerators G.edges[e][guide] (algorithms.py:155),
  *                cycled per outer iteration (algorithms.py:147); may be NULL iff max_outer_iters == 0
  *   init_tour    [B,n+1], init_cost [B]
@@ -96,6 +97,8 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  *                compact store with 32-bit counters in global memory), else the one with the largest
  *                residency.  16 = uint16 LDS counters (n=100: 3 workgroups per CU): a counter about to
  *                overflow stops that instance with GNNGLS_STATUS_PENALTY_OVERFLOW; the caller reruns it with 32.
+ *                -1 = force the global-memory store: matrices stay in HBM/L2 and every evaluation keeps the
+ *                reference's exact index order, so D may be ASYMMETRIC (the LDS stores keep one triangle).
  *   watchdog_s   hard abort (status GNNGLS_STATUS_WATCHDOG) if a workgroup runs longer than this
  *   outputs      best_tour [B,n+1], best_cost [B], outer_iters [B] (int64),
  *                trace_cost [B,trace_cap] cost after every accepted move (algorithms.py:127-130,

@@ -92,3 +92,10 @@ def test_operators_accept_asymmetric_matrices(n):
             od, ot, _ = getattr(go, name + "_o2a")(tour, D, n // 2, fi)
             assert np.float64(delta.item()).tobytes() == np.float64(od).tobytes() and nt[0].cpu().tolist() == ot
     assert np.float64(ops.tour_cost(t, d).item()).tobytes() == np.float64(go.tour_cost(tour, D)).tobytes()
+
+
+def test_local_search_mirror_rejects_asymmetric():
+    from gnngls_amd import algorithms as alg
+    D = np.random.default_rng(0).random((6, 6))
+    with pytest.raises(NotImplementedError):
+        alg.local_search([0, 1, 2, 3, 4, 5, 0], 1.0, D)
