@@ -122,7 +122,7 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         G = guides.shape[0]
     assert init_cost.dtype == torch.float64 and init_cost.shape == (B,)
     if watchdog_s is None:
-        watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 120.0
+        watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 60.0
     best_tour = torch.empty_like(init_tour)
     best_cost = torch.empty((B,), dtype=torch.float64, device=dev)
     outer = torch.zeros((B,), dtype=torch.int64, device=dev)
