@@ -446,6 +446,71 @@ __device__ __forceinline__ void scan_relocate_a2a(const S &s, const TT *t, const
     }
 }
 
+// a2a scans, "row on the lane" mapping: lane l of row-wave rw owns tour row i = 1 + 64*rw + l for the whole scan (its
+// row constants stay in registers), and the wavefront walks j uniformly (j-groups of waves take j strided).  The
+// tour bytes and edge lengths of position j are wave-uniform (one broadcast LDS read, moved to SGPRs), so an evaluation is
+// ONE dependent LDS round trip (the two random distance reads) instead of tour bytes -> index -> distances, with
+// no per-row prologue.  Same deltas, same keys, same arg-min as the row-per-wavefront scans above.
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_two_opt_a2a_rowlane(const S &s, const TT *t, const double *Eb, int n,
+                                                         int wave, int nwaves, int lane, double &bd, int &bk) {
+    const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows
+    const int JG = nwaves / RW > 0 ? nwaves / RW : 1;        // wave groups sharing a row block, striding over j
+    const int RWE = nwaves / JG;
+    const int rw = __builtin_amdgcn_readfirstlane(wave % RWE), jg = __builtin_amdgcn_readfirstlane(wave / RWE);
+    if (jg >= JG) return;
+    for (int rb = rw; rb < RW; rb += RWE) {
+        const int i = 1 + rb * kWave + lane;
+        const bool row_ok = i <= n - 3;                      // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39)
+        const int ic = row_ok ? i : 1;
+        const int a = t[ic], b = t[ic - 1];
+        const double eab = Eb[ic];                           // D[a,b]
+        const int jlo = 3 + rb * kWave;                      // smallest j any lane of this block can use (i+2, i >= 1+64rb)
+        for (int j = jlo + jg; j <= n - 1; j += JG) {
+            const int c = __builtin_amdgcn_readfirstlane((int)t[j]), d = __builtin_amdgcn_readfirstlane((int)t[j - 1]);
+            const double ecd = Eb[j];                        // D[c,d] (uniform address: broadcast)
+            if (row_ok && j >= i + 2) {
+                double delta = s.dist(a, c) + s.dist(b, d);
+                delta = delta - eab;
+                delta = delta - ecd;
+                consider<FI>(delta, make_key(i, j), bd, bk);
+            }
+        }
+    }
+}
+
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *t, const double *Ef, int n,
+                                                          int wave, int nwaves, int lane, double &bd, int &bk) {
+    const int RW = (n - 1 + kWave - 1) / kWave;
+    const int JG = nwaves / RW > 0 ? nwaves / RW : 1;
+    const int RWE = nwaves / JG;
+    const int rw = __builtin_amdgcn_readfirstlane(wave % RWE), jg = __builtin_amdgcn_readfirstlane(wave / RWE);
+    if (jg >= JG) return;
+    for (int rb = rw; rb < RW; rb += RWE) {
+        const int i = 1 + rb * kWave + lane;
+        const bool row_ok = i <= n - 1;                      // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
+        const int ic = row_ok ? i : 1;
+        const int a = t[ic - 1], b = t[ic], cc = t[ic + 1];
+        double base = -Ef[ic];                               // -D[a,b]
+        base = base - Ef[ic + 1];                            // -D[b,c]
+        base = base + s.dist(a, cc);                         // +D[a,c]
+        for (int j = 1 + jg; j <= n - 1; j += JG) {
+            const int tjm = __builtin_amdgcn_readfirstlane((int)t[j - 1]);
+            const int tj = __builtin_amdgcn_readfirstlane((int)t[j]);
+            const int tjp = __builtin_amdgcn_readfirstlane((int)t[j + 1]);
+            const double ej = Ef[j], ejp = Ef[j + 1];
+            if (row_ok && j != i && j != i - 1) {
+                const int d = i < j ? tj : tjm, e = i < j ? tjp : tj;
+                double delta = base - (i < j ? ejp : ej);    // -D[d,e]
+                delta = delta + s.dist(d, b);
+                delta = delta + s.dist(b, e);
+                consider<FI>(delta, make_key(i, j), bd, bk);
+            }
+        }
+    }
+}
+
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
@@ -585,8 +650,15 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
-            if (op == 0) scan_two_opt_a2a<S, FI, TT, S::kScanUnroll>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
-            else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+            // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
+            // software-pipelining the uniform operands one step ahead costs registers: 9.6k at TSP100
+            if (S::kScanUnroll == 1 && n - 1 <= 2 * kWave) {
+                if (op == 0) scan_two_opt_a2a_rowlane<S, FI, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                else         scan_relocate_a2a_rowlane<S, FI, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+            } else {
+                if (op == 0) scan_two_opt_a2a<S, FI, TT, S::kScanUnroll>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+            }
             block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
