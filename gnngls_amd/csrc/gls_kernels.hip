@@ -90,6 +90,8 @@ struct TriStore {
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
+    // index with the triangular row offsets precomputed: a2 = a(a-1)/2 (per lane), c2 = c(c-1)/2 (wave-uniform, SALU)
+    __device__ __forceinline__ static int idx2(int a, int a2, int c, int c2) { return a > c ? a2 + c : c2 + a; }
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     int limit;         // largest representable count (65535 for 16-bit counters; lowered only by the test hook)
@@ -124,6 +126,8 @@ struct TriDGlobalP {
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
+    // index with the triangular row offsets precomputed: a2 = a(a-1)/2 (per lane), c2 = c(c-1)/2 (wave-uniform, SALU)
+    __device__ __forceinline__ static int idx2(int a, int a2, int c, int c2) { return a > c ? a2 + c : c2 + a; }
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
@@ -140,6 +144,7 @@ struct GlobalStore {
     int n;
     static constexpr bool kSymmetric = false;
     __device__ __forceinline__ int idx(int a, int b) const { return a * n + b; }
+    __device__ __forceinline__ int idx2(int a, int, int c, int) const { return a * n + c; }
     __device__ __forceinline__ double dist(int a, int b) const { return d[(size_t)a * n + b]; }
     __device__ __forceinline__ int pen(int a, int b) const { return p[(size_t)a * n + b]; }
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
@@ -464,13 +469,15 @@ __device__ __forceinline__ void scan_two_opt_a2a_rowlane(const S &s, const TT *t
         const bool row_ok = i <= n - 3;                      // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39)
         const int ic = row_ok ? i : 1;
         const int a = t[ic], b = t[ic - 1];
+        const int a2 = (a * (a - 1)) >> 1, b2 = (b * (b - 1)) >> 1;     // triangular row offsets, once per scan
         const double eab = Eb[ic];                           // D[a,b]
         const int jlo = 3 + rb * kWave;                      // smallest j any lane of this block can use (i+2, i >= 1+64rb)
         for (int j = jlo + jg; j <= n - 1; j += JG) {
             const int c = __builtin_amdgcn_readfirstlane((int)t[j]), d = __builtin_amdgcn_readfirstlane((int)t[j - 1]);
+            const int c2 = (c * (c - 1)) >> 1, d2 = (d * (d - 1)) >> 1;   // wave-uniform: scalar ALU
             const double ecd = Eb[j];                        // D[c,d] (uniform address: broadcast)
             if (row_ok && j >= i + 2) {
-                double delta = s.dist(a, c) + s.dist(b, d);
+                double delta = s.dist_at(s.idx2(a, a2, c, c2)) + s.dist_at(s.idx2(b, b2, d, d2));
                 delta = delta - eab;
                 delta = delta - ecd;
                 consider<FI>(delta, make_key(i, j), bd, bk);
@@ -495,16 +502,19 @@ __device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *
         double base = -Ef[ic];                               // -D[a,b]
         base = base - Ef[ic + 1];                            // -D[b,c]
         base = base + s.dist(a, cc);                         // +D[a,c]
+        const int b2 = (b * (b - 1)) >> 1;
         for (int j = 1 + jg; j <= n - 1; j += JG) {
             const int tjm = __builtin_amdgcn_readfirstlane((int)t[j - 1]);
             const int tj = __builtin_amdgcn_readfirstlane((int)t[j]);
             const int tjp = __builtin_amdgcn_readfirstlane((int)t[j + 1]);
+            const int tjm2 = (tjm * (tjm - 1)) >> 1, tj2 = (tj * (tj - 1)) >> 1, tjp2 = (tjp * (tjp - 1)) >> 1;
             const double ej = Ef[j], ejp = Ef[j + 1];
             if (row_ok && j != i && j != i - 1) {
                 const int d = i < j ? tj : tjm, e = i < j ? tjp : tj;
+                const int d2 = i < j ? tj2 : tjm2, e2 = i < j ? tjp2 : tj2;
                 double delta = base - (i < j ? ejp : ej);    // -D[d,e]
-                delta = delta + s.dist(d, b);
-                delta = delta + s.dist(b, e);
+                delta = delta + s.dist_at(s.idx2(b, b2, d, d2));   // +D[d,b] (symmetric stores) / D[b,d] index order n/a here
+                delta = delta + s.dist_at(s.idx2(b, b2, e, e2));   // +D[b,e]
                 consider<FI>(delta, make_key(i, j), bd, bk);
             }
         }
@@ -652,7 +662,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
             double bd = 0.0; int bk = kNoKey;
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
             // software-pipelining the uniform operands one step ahead costs registers: 9.6k at TSP100
-            if (S::kScanUnroll == 1 && n - 1 <= 2 * kWave) {
+            if (S::kScanUnroll == 1 && S::kSymmetric && n - 1 <= 2 * kWave) {
                 if (op == 0) scan_two_opt_a2a_rowlane<S, FI, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                 else         scan_relocate_a2a_rowlane<S, FI, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             } else {
