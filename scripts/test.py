@@ -1,21 +1,21 @@
 #!/usr/bin/env python
 # coding: utf-8
-"""Drop-in for the reference's scripts/test.py (test.py:20-123): same positional arguments and flags,
-same per-instance semantics (10 s budget that starts before the forward pass, nearest-neighbour
-start on the guide, guided_local_search, gap vs the Concorde optimum stored in the instances) and
-the same DataFrame pickle (columns instance,time,opt_cost,cost,best_cost,gap,dt).
+"""Evaluation entry point with the command line and the output of the reference's scripts/test.py
+(test.py:20-123): `test.py data_path model_path run_dir guides... [--time_limit 10.] [--perturbation_moves 20]
+[--use_gpu]`, per-instance semantics unchanged (the budget starts before the forward pass, nearest-neighbour start
+on the first guide, guided_local_search, gap vs the optimum stored in the instances) and the same DataFrame pickle
+(columns instance, time, opt_cost, cost, best_cost, gap, dt) in `run_dir/<timestamp>_<uuid>.pkl`.
 
-The per-instance loop of the reference (test.py:59) is replaced by batches on the GPU: every instance
-of a batch gets the full --time_limit concurrently (gnngls_amd.pipeline.solve_batch).  `--use_gpu`
-is accepted for compatibility; this implementation always runs on the GPU and has no CPU path.
-
-Multi-GPU: launched under torchrun (one process per GPU) the instance list is split into contiguous
-blocks (gnngls_amd.parallel.shard_range), every rank searches its block, and the per-instance records
-are gathered once on rank 0, which writes the single DataFrame.
+What differs is the execution: instead of one instance at a time (test.py:59) whole batches are searched on the GPU,
+every instance of a batch getting the full --time_limit concurrently (gnngls_amd.pipeline.solve_batch).  `--use_gpu`
+is accepted for compatibility; there is no CPU path.  Under torchrun (one process per GPU) the instance list is
+split into contiguous blocks (gnngls_amd.parallel.shard_range), every rank searches its block, and rank 0 gathers
+the records once and writes the single DataFrame.
 """
 import argparse
 import datetime
 import json
+import os
 import pathlib
 import sys
 import time
@@ -24,19 +24,19 @@ import uuid
 import numpy as np
 import pandas as pd
 import torch
+import torch.distributed as dist
 import tqdm.auto as tqdm
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 
-import os  # noqa: E402
-
-import torch.distributed as dist  # noqa: E402
-
 import gnngls_amd  # noqa: E402
-from gnngls_amd import datasets, models, parallel, pipeline  # noqa: E402
+from gnngls_amd import datasets, models, ops, parallel, pipeline  # noqa: E402
 from gnngls_amd.algorithms import _attr_matrix  # noqa: E402
 
-if __name__ == '__main__':
+TRACE_CAP = 1 << 14
+
+
+def parse_args():
     parser = argparse.ArgumentParser(description='Test model')
     parser.add_argument('data_path', type=pathlib.Path)
     parser.add_argument('model_path', type=pathlib.Path)
@@ -46,77 +46,101 @@ if __name__ == '__main__':
     parser.add_argument('--perturbation_moves', type=int, default=20)
     parser.add_argument('--use_gpu', action='store_true')
     parser.add_argument('--batch_size', type=int, default=0, help='instances searched concurrently (0 = device capacity)')
-    args = parser.parse_args()
+    return parser.parse_args()
 
+
+def init_ranks():
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
     if world > 1:
         dist.init_process_group(os.environ.get('GNNGLS_DIST_BACKEND', 'nccl'))
+    return world, rank
 
-    params = json.load(open(args.model_path.parent / 'params.json'))
-    if 'efeat_drop_idx' in params:
-        test_set = datasets.TSPDataset(args.data_path, feat_drop_idx=params['efeat_drop_idx'])
-    else:
-        test_set = datasets.TSPDataset(args.data_path)
 
-    model, scalers = None, None
-    if 'regret_pred' in args.guides:
-        device = torch.device('cuda')
-        print('device =', device)
-        model = models.EdgePropertyPredictionModel(1, params['embed_dim'], 1, params['n_layers'],
-                                                   n_heads=params['n_heads']).to(device)
-        if datasets.is_lfs_pointer(args.model_path):
-            raise FileNotFoundError(f'{args.model_path} is a git-LFS pointer stub')
-        checkpoint = torch.load(args.model_path, map_location=device)
-        model.load_state_dict(checkpoint['model_state_dict'])
-        model.eval()
-        scalers = pipeline.Scalers.from_sklearn(test_set.scalers)
+def load_model(args, params, test_set):
+    """test.py:37-54: architecture from params.json, weights from checkpoint['model_state_dict']."""
+    if 'regret_pred' not in args.guides:
+        return None, None
+    device = torch.device('cuda')
+    print('device =', device)
+    if datasets.is_lfs_pointer(args.model_path):
+        raise FileNotFoundError(f'{args.model_path} is a git-LFS pointer stub')
+    model = models.EdgePropertyPredictionModel(1, params['embed_dim'], 1, params['n_layers'], n_heads=params['n_heads'])
+    state = torch.load(args.model_path, map_location=device)['model_state_dict']
+    model.load_state_dict(state)
+    return model.to(device).eval(), pipeline.Scalers.from_sklearn(test_set.scalers)
 
-    n = test_set.G.n
-    bs = args.batch_size or max(gnngls_amd.ops.gls_resident_capacity(n), 1)
+
+def solve_block(names, test_set, model, scalers, args, chunk):
+    """One batch of instances -> (search-progress records, gaps), the body of the loop at test.py:59-109."""
+    graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
+    optima = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
+    D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
+    started = time.time()                                                     # the budget starts here (test.py:64)
+    records = [{'instance': name, 'time': started, 'opt_cost': opt} for name, opt in zip(names, optima)]
+    res = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
+                               perturbation_moves=args.perturbation_moves, trace_cap=TRACE_CAP, want_trace_time=True,
+                               chunk=chunk)
+    moves = res.moves.cpu().numpy()
+    costs, stamps = res.trace_cost.cpu().numpy(), res.trace_time.cpu().numpy()
     gaps = []
-    search_progress = []
-    lo, hi = parallel.shard_range(len(test_set.instances), world, rank)      # this rank's block of instances
-    my_instances = test_set.instances[lo:hi]
-    pbar = tqdm.tqdm(total=len(my_instances), disable=rank != 0)
-    for b0 in range(0, len(my_instances), bs):
-        names = my_instances[b0:b0 + bs]
-        graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
-        opt_costs = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
-        D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
-        t = time.time()
-        for name, opt_cost in zip(names, opt_costs):
-            search_progress.append({'instance': name, 'time': t, 'opt_cost': opt_cost})
-        r = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
-                                 perturbation_moves=args.perturbation_moves, trace_cap=1 << 14, want_trace_time=True,
-                                 chunk=bs)
-        trace_len = r.moves.cpu().numpy()
-        trace_cost, trace_time = r.trace_cost.cpu().numpy(), r.trace_time.cpu().numpy()
-        for i, (name, opt_cost) in enumerate(zip(names, opt_costs)):
-            L = min(int(trace_len[i]), trace_cost.shape[1])
-            for c, dt_ in zip(trace_cost[i, :L], trace_time[i, :L]):
-                search_progress.append({'instance': name, 'opt_cost': opt_cost, 'time': t + float(dt_), 'cost': float(c)})
-            gaps.append((r.best_cost[i].item() / opt_cost - 1) * 100)
-        pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})
-        pbar.update(len(names))
-    pbar.close()
+    for k, (name, opt) in enumerate(zip(names, optima)):
+        kept = min(int(moves[k]), costs.shape[1])
+        records += [{'instance': name, 'opt_cost': opt, 'time': started + float(dt), 'cost': float(c)}
+                    for c, dt in zip(costs[k, :kept], stamps[k, :kept])]
+        gaps.append((res.best_cost[k].item() / opt - 1) * 100)                # test.py:104
+    return records, gaps
 
-    if world > 1:                                   # one gather of the per-instance records
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(search_progress, parts, dst=0)
-        dist.barrier()
-        dist.destroy_process_group()
-        if rank != 0:
-            sys.exit(0)
-        search_progress = [row for part in parts for row in part]
 
-    search_progress_df = pd.DataFrame.from_records(search_progress)
-    search_progress_df['best_cost'] = search_progress_df.groupby('instance')['cost'].cummin()
-    search_progress_df['gap'] = (search_progress_df['best_cost'] / search_progress_df['opt_cost'] - 1) * 100
-    search_progress_df['dt'] = search_progress_df['time'] - search_progress_df.groupby('instance')['time'].transform('min')
+def gather_records(records, world, rank):
+    if world == 1:
+        return records
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(records, parts, dst=0)                                 # the one exchange of the run
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank != 0:
+        return None
+    return [row for part in parts for row in part]
 
-    timestamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
-    run_name = f'{timestamp}_{uuid.uuid4().hex}.pkl'
-    if not args.run_dir.exists():
-        args.run_dir.mkdir()
-    search_progress_df.to_pickle(args.run_dir / run_name)
+
+def write_progress(records, run_dir):
+    """test.py:113-123."""
+    df = pd.DataFrame.from_records(records)
+    by_instance = df.groupby('instance')
+    df['best_cost'] = by_instance['cost'].cummin()
+    df['gap'] = (df['best_cost'] / df['opt_cost'] - 1) * 100
+    df['dt'] = df['time'] - by_instance['time'].transform('min')
+    stamp = datetime.datetime.now().strftime('%b%d_%H-%M-%S')
+    if not run_dir.exists():
+        run_dir.mkdir()
+    df.to_pickle(run_dir / f'{stamp}_{uuid.uuid4().hex}.pkl')
+
+
+def main():
+    args = parse_args()
+    world, rank = init_ranks()
+    params = json.load(open(args.model_path.parent / 'params.json'))
+    test_set = datasets.TSPDataset(args.data_path, feat_drop_idx=params.get('efeat_drop_idx', []))
+    model, scalers = load_model(args, params, test_set)
+
+    chunk = args.batch_size or max(ops.gls_resident_capacity(test_set.G.n), 1)
+    lo, hi = parallel.shard_range(len(test_set.instances), world, rank)       # this rank's block of instances
+    mine = test_set.instances[lo:hi]
+    records, gaps = [], []
+    with tqdm.tqdm(total=len(mine), disable=rank != 0) as pbar:
+        for start in range(0, len(mine), chunk):
+            names = mine[start:start + chunk]
+            rec, g = solve_block(names, test_set, model, scalers, args, chunk)
+            records += rec
+            gaps += g
+            pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})
+            pbar.update(len(names))
+
+    records = gather_records(records, world, rank)
+    if records is not None:
+        write_progress(records, args.run_dir)
+
+
+if __name__ == '__main__':
+    main()
