@@ -249,8 +249,52 @@ def main():
         np.savez_compressed(os.path.join(GOLD, f"model_n{n}.npz"), x=x.numpy(), y=y.numpy(),
                             model_seed=1234, sd_seed=99, sd_checksum=np.float64(checksum),
                             n_params=sum(p.numel() for p in ref_model.parameters()))
+    gen_train(ref)
     print("golden vectors written to", GOLD)
 
 
+TRAIN_CASES = ((5, 3), (8, 2))            # (n, batch)
+SAMPLE = 129                              # gradient entries kept per parameter (stride sample) + sum / abs-sum
+
+
+def grad_digest(g):
+    """Compact pin of one gradient tensor: fp64 sum, abs-sum and a strided sample of its entries."""
+    import numpy as np
+    flat = g.detach().double().reshape(-1).numpy()
+    idx = np.unique(np.linspace(0, flat.size - 1, min(SAMPLE, flat.size)).astype(np.int64))
+    return np.float64(flat.sum()), np.float64(np.abs(flat).sum()), idx.astype(np.int32), flat[idx].astype(np.float32)
+
+
+def gen_train(ref):
+    """(9) one training step (train.py:20-32: model.train(), MSELoss, loss.backward()) through the reference's own
+    models.py on a dgl.batch-style disjoint union of line graphs: predictions, loss, a digest of every parameter
+    gradient and the BatchNorm running statistics after the step -> tests/golden/train_n{n}.npz."""
+    import torch
+    from oracle import model_oracle as mo
+
+    for n, batch in TRAIN_CASES:
+        torch.manual_seed(4321)
+        model = ref.models.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+        sd = mo.synthetic_state_dict(model, seed=77)
+        model.load_state_dict(sd)
+        rng = np.random.default_rng(1000 + n)
+        N = n * (n - 1) // 2
+        x = torch.from_numpy(rng.random((batch * N, 1)).astype(np.float32))
+        target = torch.from_numpy(rng.random((batch * N, 1)).astype(np.float32))
+        G = mo.batch_line_graphs(n, batch)
+        y, loss, grads, bufs = mo.train_step_reference(model, G, x, target)
+        out = dict(x=x.numpy(), target=target.numpy(), y=y.numpy(), loss=np.float32(loss.item()), n=n, batch=batch,
+                   model_seed=4321, sd_seed=77)
+        for k, g in grads.items():
+            s, a, idx, val = grad_digest(g)
+            out["gsum/" + k], out["gabs/" + k], out["gidx/" + k], out["gval/" + k] = s, a, idx, val
+        for k, b in bufs.items():
+            out["buf/" + k] = b.numpy()
+        np.savez_compressed(os.path.join(GOLD, f"train_n{n}.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-train" in sys.argv:          # adds the training fixtures without rewriting the others
+        gen_train(ref_import.import_reference(with_models=True))
+    else:
+        main()

@@ -83,6 +83,17 @@ def line_graph_networkx(n):
     return LineGraph(n, torch.tensor(src, dtype=torch.int64), torch.tensor(dst, dtype=torch.int64), e)
 
 
+def batch_line_graphs(n, batch):
+    """Disjoint union of `batch` copies of the line graph of K_n -- what dgl.batch (train.py:118-121) hands to the
+    model: node ids of instance b are offset by b*N, arcs never cross instances."""
+    g = line_graph_networkx(n)
+    N = g.number_of_nodes()
+    off = (torch.arange(batch, dtype=torch.int64) * N)[:, None]
+    src = (g.src[None, :] + off).reshape(-1)
+    dst = (g.dst[None, :] + off).reshape(-1)
+    return LineGraph(n, src, dst, g.ndata["e"].repeat(batch, 1))
+
+
 class GATConvOracle(nn.Module):
     """dgl.nn.GATConv(in_feats, out_feats, num_heads) as called at gnngls/models.py:23, DGL 0.6.1
     defaults: feat_drop=attn_drop=0, negative_slope=0.2, residual=False, activation=None, no bias.
@@ -206,6 +217,21 @@ def synthetic_state_dict(model, seed):
         else:
             out[k] = v.clone()
     return out
+
+
+def train_step_reference(model, G, x, target, criterion=None):
+    """One optimisation step's forward/backward exactly as train.py:20-32 runs it (model.train(); y_pred = model(batch, x);
+    loss = criterion(y_pred, y); loss.backward()), on CPU through torch autograd.
+    -> (y_pred, loss, {param name: grad}, {buffer name: value after the step})."""
+    criterion = criterion or nn.MSELoss()
+    model.train()
+    model.zero_grad()
+    y = model(G, x)
+    loss = criterion(y, target.type_as(y))
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    bufs = {k: b.detach().clone() for k, b in model.named_buffers()}
+    return y.detach(), loss.detach(), grads, bufs
 
 
 def minmax_transform(x, scale_, min_):

@@ -80,3 +80,37 @@ def test_minmax_scaler_fp32():
     inv = (g["scaler_inv_in"].astype(np.float64) - m).astype(np.float32)
     inv = (inv.astype(np.float64) / s).astype(np.float32)
     assert np.array_equal(inv, g["scaler_inv"])
+
+
+@pytest.mark.parametrize("n", [5, 8])
+def test_train_step_matches_reference_golden(n):
+    """One training step (train.py:20-32) of the oracle's own wiring vs the fixture captured from the reference's
+    models.py: predictions, loss, every parameter gradient (sum, abs-sum, strided sample) and the BatchNorm running
+    statistics after the step."""
+    g = np.load(os.path.join(GOLD, f"train_n{n}.npz"))
+    torch.manual_seed(int(g["model_seed"]))
+    model = mo.EdgeRegretModelOracle(1, 128, 1, 3, n_heads=8)
+    model.load_state_dict(mo.synthetic_state_dict(model, seed=int(g["sd_seed"])))
+    G = mo.batch_line_graphs(n, int(g["batch"]))
+    y, loss, grads, bufs = mo.train_step_reference(model, G, torch.from_numpy(g["x"]), torch.from_numpy(g["target"]))
+    # same torch ops in the same wiring; CPU scatter/GEMM reductions are multi-threaded, so allow fp32 reordering noise
+    assert np.allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6) and abs(loss.item() - g["loss"]) <= 1e-6 * g["loss"]
+    for k, gr in grads.items():
+        flat = gr.double().reshape(-1).numpy()
+        scale = float(g["gabs/" + k])
+        # (a Linear bias feeding a BatchNorm has an exactly zero gradient: what is stored there is rounding noise)
+        noise = 1e-6 * flat.size
+        assert abs(flat.sum() - g["gsum/" + k]) <= 1e-5 * scale + noise, k
+        assert abs(np.abs(flat).sum() - scale) <= 1e-5 * scale + noise, k
+        assert np.allclose(flat[g["gidx/" + k]], g["gval/" + k], rtol=1e-4, atol=1e-4 * np.abs(flat).max() + 1e-6), k
+    for k, b in bufs.items():
+        assert np.allclose(b.numpy(), g["buf/" + k], rtol=1e-5, atol=1e-7), k
+
+
+def test_batched_line_graph_is_disjoint_union():
+    n, B = 6, 3
+    G1, GB = mo.line_graph_networkx(n), mo.batch_line_graphs(n, B)
+    N = G1.number_of_nodes()
+    assert GB.number_of_nodes() == B * N and len(GB.src) == B * len(G1.src)
+    assert torch.equal(GB.src // N, GB.dst // N)                      # no arc crosses instances
+    assert torch.equal(GB.src[:len(G1.src)], G1.src) and torch.equal(GB.dst[-len(G1.dst):] - (B - 1) * N, G1.dst)
