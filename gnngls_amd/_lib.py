@@ -12,6 +12,7 @@ _vp = ctypes.c_void_p
 _int = ctypes.c_int
 _i64 = ctypes.c_int64
 _f64 = ctypes.c_double
+_f32 = ctypes.c_float
 
 # name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPES
 SIGNATURES = {
@@ -29,6 +30,9 @@ SIGNATURES = {
     "gnngls_model_packed_floats": [_int, _int],
     "gnngls_regret_forward_workspace_bytes": [_int, _int],
     "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
+    "gnngls_regret_train_workspace_bytes": [_int, _int, _int],
+    "gnngls_regret_train_forward": [_vp, _vp, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _i64, _vp],
+    "gnngls_regret_train_backward": [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
     "gnngls_pack_features": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_debug_set_penalty16_limit": [_int],
@@ -38,7 +42,8 @@ SIGNATURES = {
 }
 
 PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine(unused)", "gemm_ffn1(unused)", "gemm_ffn2(unused)",
-              "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls", "ffn_fused"]
+              "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls", "ffn_fused",
+              "train_colsum", "train_elementwise", "train_gemm_bwd", "train_gemm_tn", "train_gat_bwd"]
 
 
 def profile_enable(on=True):
@@ -54,7 +59,8 @@ def profile_collect():
           "profile_collect")
     return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 _RESTYPES = {"gnngls_last_error": ctypes.c_char_p, "gnngls_model_packed_floats": ctypes.c_int64,
-             "gnngls_regret_forward_workspace_bytes": ctypes.c_int64}
+             "gnngls_regret_forward_workspace_bytes": ctypes.c_int64,
+             "gnngls_regret_train_workspace_bytes": ctypes.c_int64}
 
 _lib = None
 

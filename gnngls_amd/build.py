@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libgnngls_hip.so")
-SOURCES = ["gls_kernels.hip", "model_kernels.hip", "capi.hip"]
+SOURCES = ["gls_kernels.hip", "model_kernels.hip", "train_kernels.hip", "capi.hip"]
 # -ffp-contract=off: the guided matrix D + k*P (gnngls/algorithms.py:164) rounds twice and np.isclose
 # (operators.py:42) is evaluated literally; a fused multiply-add would change move selection.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -12,6 +12,7 @@
 #include "../../include/gnngls_hip.h"
 #include "gls_kernels.h"
 #include "model_kernels.h"
+#include "train_kernels.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -300,6 +301,237 @@ int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_
     hipError_t e = gnngls::launch_unpack_regret(y, B, n, scale, min_, out, (hipStream_t)stream);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "unpack_regret");
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// GNN training step (forward with batch-statistics BatchNorm + backward)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// Device workspace of one training step for M = B*N rows and L layers.  The first group is written by the forward and
+// read by the backward (it must survive between the two calls); the second group is scratch.
+struct TrainWs {
+    float *H;        // [(L+1)][M][128]  layer inputs (H[0] = embedding) and the final hidden state
+    float *FT;       // [L][M][128]      fc(h)
+    float *G;        // [L][M][128]      GATConv output
+    float *H1;       // [L][M][128]      h + GATConv(h)
+    float *H3;       // [L][M][128]      x + MLP(x), x = BN1(h1)
+    float *ATT;      // [L][M][16]       softmax statistics (row max, 1/Z) per head
+    float *BN;       // [L][8][128]      mean1 invstd1 scale1 shift1 mean2 invstd2 scale2 shift2
+    float *PART;     // [2][M][128]      attention partials (forward) / P partials (backward)
+    float *PMS;      // [2][M][16]
+    float *DA, *DB;  // [M][128]         gradient ping-pong
+    float *X2;       // [M][128]         BN1 output recomputed in the backward
+    float *DFT;      // [M][128]
+    float *DLR;      // [2][M][8]        d el, d er
+    float *BIG;      // [M][512]         hidden activations / their gradient
+    float *COEF;     // [5][128]         BatchNorm backward coefficients (3), ones, zeros
+    double *CSP;     // column-sum partials
+    float *TNP;      // weight-gradient partial tiles
+    size_t bytes;
+};
+
+TrainWs train_layout(uintptr_t base, long M, int L) {
+    TrainWs w;
+    uintptr_t p = (base + 255) & ~(uintptr_t)255;
+    auto take = [&](size_t bytes) { uintptr_t q = p; p = (p + bytes + 255) & ~(uintptr_t)255; return q; };
+    const size_t row = (size_t)M * 128 * sizeof(float);
+    w.H = (float *)take(row * (L + 1));
+    w.FT = (float *)take(row * L);
+    w.G = (float *)take(row * L);
+    w.H1 = (float *)take(row * L);
+    w.H3 = (float *)take(row * L);
+    w.ATT = (float *)take((size_t)M * 16 * sizeof(float) * L);
+    w.BN = (float *)take((size_t)L * 8 * 128 * sizeof(float));
+    w.PART = (float *)take(2 * row);
+    w.PMS = (float *)take((size_t)2 * M * 16 * sizeof(float));
+    w.DA = (float *)take(row);
+    w.DB = (float *)take(row);
+    w.X2 = (float *)take(row);
+    w.DFT = (float *)take(row);
+    w.DLR = (float *)take((size_t)2 * M * 8 * sizeof(float));
+    w.BIG = (float *)take(4 * row);
+    w.COEF = (float *)take(5 * 128 * sizeof(float));
+    w.CSP = (double *)take((size_t)gnngls::kColsumMaxBlocks * 2 * 512 * sizeof(double));
+    w.TNP = (float *)take((size_t)gnngls::gemm_tn_chunks(M) * 128 * 512 * sizeof(float));
+    w.bytes = (size_t)(p - base);
+    return w;
+}
+
+struct LayerParams {
+    const float *fc_w, *attn_l, *attn_r, *bn1_g, *bn1_b, *w1, *b1, *w2, *b2, *bn2_g, *bn2_b;
+};
+
+template <typename T>
+void layer_pointers(T *w, T *&fc_w, T *&attn_l, T *&attn_r, T *&bn1_g, T *&bn1_b, T *&w1, T *&b1, T *&w2, T *&b2, T *&bn2_g,
+                    T *&bn2_b) {
+    fc_w = w; attn_l = fc_w + 128L * 128; attn_r = attn_l + 128; bn1_g = attn_r + 128; bn1_b = bn1_g + 128;
+    w1 = bn1_b + 128; b1 = w1 + 512L * 128; w2 = b1 + 512; b2 = w2 + 128L * 512; bn2_g = b2 + 128; bn2_b = bn2_g + 128;
+}
+
+int train_check(const char *what, const void *feat, const void *params, const void *io, const void *workspace, int B, int n,
+                int in_dim, int n_layers, int64_t workspace_bytes) {
+    if (!feat || !params || !io || !workspace || B < 1 || n < 3 || in_dim < 1 || n_layers < 0)
+        return fail(GNNGLS_ERR_ARG, "%s: bad argument", what);
+    if (gnngls::gat_rows_lds_bytes(n) > kLdsPerCU || gnngls::gat_bwd_lds_bytes(n) > kLdsPerCU)
+        return fail(GNNGLS_ERR_UNSUPPORTED, "%s: n=%d needs %zu B of LDS per row tile (> 160 KiB)", what, n,
+                    gnngls::gat_bwd_lds_bytes(n));
+    const int64_t need = gnngls_regret_train_workspace_bytes(B, n, n_layers);
+    if (workspace_bytes < need)
+        return fail(GNNGLS_ERR_ARG, "%s: workspace too small (%lld B, need %lld B)", what, (long long)workspace_bytes,
+                    (long long)need);
+    return GNNGLS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gnngls_regret_train_workspace_bytes(int B, int n, int n_layers) {
+    if (B < 1 || n < 2 || n_layers < 0) return 0;
+    const long M = (long)B * ((long)n * (n - 1) / 2);
+    return (int64_t)train_layout(0, M, n_layers).bytes + 256;
+}
+
+#define GNNGLS_TRY(x) do { e = (x); if (e != hipSuccess) return hip_fail(e, #x); } while (0)
+
+int gnngls_regret_train_forward(const float *feat, const float *params, int B, int n, int in_dim, int n_layers, float bn_eps,
+                                float *y_out, float *bn_batch_stats, void *workspace, int64_t workspace_bytes, void *stream) {
+    int rc = train_check("regret_train_forward", feat, params, y_out, workspace, B, n, in_dim, n_layers, workspace_bytes);
+    if (rc != GNNGLS_OK) return rc;
+    if (!bn_batch_stats && n_layers > 0) return fail(GNNGLS_ERR_ARG, "regret_train_forward: bn_batch_stats is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const long N = (long)n * (n - 1) / 2, M = (long)B * N;
+    const TrainWs w = train_layout((uintptr_t)workspace, M, n_layers);
+    const float *emb_w = params, *emb_b = params + 128L * in_dim, *layers = emb_b + 128;
+    const float *dec_w = layers + (long)n_layers * kLayerFloats, *dec_b = dec_w + 128;
+    float *ones = w.COEF + 3 * 128, *zeros = w.COEF + 4 * 128;
+    hipError_t e = hipSuccess;
+    const float one = 1.f;
+    uint32_t one_bits;
+    memcpy(&one_bits, &one, 4);
+    GNNGLS_TRY(hipMemsetD32Async((hipDeviceptr_t)ones, (int)one_bits, 128, st));
+    GNNGLS_TRY(hipMemsetAsync(zeros, 0, 128 * sizeof(float), st));
+    const size_t row = (size_t)M * 128;
+    { ProfScope ps(GNNGLS_PROF_EMBED, st);
+      GNNGLS_TRY(gnngls::launch_embed(feat, emb_w, emb_b, w.H, M, in_dim, st)); }                       // models.py:66
+    for (int l = 0; l < n_layers; ++l) {                                                                // models.py:67-68
+        const float *fc_w, *attn_l, *attn_r, *bn1_g, *bn1_b, *w1, *b1, *w2, *b2, *bn2_g, *bn2_b;
+        layer_pointers(layers + (long)l * kLayerFloats, fc_w, attn_l, attn_r, bn1_g, bn1_b, w1, b1, w2, b2, bn2_g, bn2_b);
+        const float *h = w.H + row * l;
+        float *ft = w.FT + row * l, *g = w.G + row * l, *h1 = w.H1 + row * l, *h3 = w.H3 + row * l;
+        float *att = w.ATT + (size_t)M * 16 * l, *bn = w.BN + (size_t)l * 8 * 128;
+        float *stats = bn_batch_stats + (size_t)l * 4 * 128;
+        int nb = 0;
+        { ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
+          GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
+        { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
+          GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, B, n, w.PART, w.PMS, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+          GNNGLS_TRY(gnngls::launch_gat_combine_train(w.PART, w.PMS, h, M, g, h1, att, st)); }          // models.py:12-15
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);                                                   // models.py:27 (train mode)
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_SQ, h1, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_bn_stats_finalize(w.CSP, nb, M, bn1_g, bn1_b, bn_eps, bn + 2 * 128, bn + 3 * 128, bn,
+                                                      bn + 128, stats, stats + 128, st)); }
+        { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);                                                      // models.py:28-33
+          GNNGLS_TRY(gnngls::launch_ffn_fused_pre(h1, bn + 2 * 128, bn + 3 * 128, w1, b1, w2, b2, ones, zeros, h3, M, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);                                                   // models.py:35 (train mode)
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_SQ, h3, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_bn_stats_finalize(w.CSP, nb, M, bn2_g, bn2_b, bn_eps, bn + 6 * 128, bn + 7 * 128,
+                                                      bn + 4 * 128, bn + 5 * 128, stats + 256, stats + 384, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+          GNNGLS_TRY(gnngls::launch_affine_cols(h3, bn + 6 * 128, bn + 7 * 128, w.H + row * (l + 1), M, st)); }
+    }
+    { ProfScope ps(GNNGLS_PROF_DECISION, st);
+      GNNGLS_TRY(gnngls::launch_decision(w.H + row * n_layers, dec_w, dec_b, y_out, M, st)); }          // models.py:69
+    return GNNGLS_OK;
+}
+
+int gnngls_regret_train_backward(const float *feat, const float *params, const float *dy, int B, int n, int in_dim,
+                                 int n_layers, float *grads, void *workspace, int64_t workspace_bytes, void *stream) {
+    int rc = train_check("regret_train_backward", feat, params, grads, workspace, B, n, in_dim, n_layers, workspace_bytes);
+    if (rc != GNNGLS_OK) return rc;
+    if (!dy) return fail(GNNGLS_ERR_ARG, "regret_train_backward: dy is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const long N = (long)n * (n - 1) / 2, M = (long)B * N;
+    const TrainWs w = train_layout((uintptr_t)workspace, M, n_layers);
+    const float *layers = params + 128L * in_dim + 128;
+    const float *dec_w = layers + (long)n_layers * kLayerFloats;
+    float *g_emb_w = grads, *g_emb_b = grads + 128L * in_dim, *g_layers = g_emb_b + 128;
+    float *g_dec_w = g_layers + (long)n_layers * kLayerFloats, *g_dec_b = g_dec_w + 128;
+    const size_t row = (size_t)M * 128;
+    hipError_t e = hipSuccess;
+    int nb = 0;
+    GNNGLS_TRY(hipMemsetAsync(g_dec_b + 1, 0, 3 * sizeof(float), st));                                   // pad
+    // decision layer (models.py:69): y = h.w + b
+    { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+      GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_ROWSCALE, w.H + row * n_layers, dy, nullptr, M, 128, 1, w.CSP, &nb, st));
+      GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, g_dec_w, nullptr, st));
+      GNNGLS_TRY(gnngls::launch_sum_vector(dy, M, g_dec_b, st)); }
+    { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+      GNNGLS_TRY(gnngls::launch_outer_rows(dy, dec_w, w.DA, M, st)); }
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const float *fc_w, *attn_l, *attn_r, *bn1_g, *bn1_b, *w1, *b1, *w2, *b2, *bn2_g, *bn2_b;
+        layer_pointers(layers + (long)l * kLayerFloats, fc_w, attn_l, attn_r, bn1_g, bn1_b, w1, b1, w2, b2, bn2_g, bn2_b);
+        float *d_fc_w, *d_attn_l, *d_attn_r, *d_bn1_g, *d_bn1_b, *d_w1, *d_b1, *d_w2, *d_b2, *d_bn2_g, *d_bn2_b;
+        layer_pointers(g_layers + (long)l * kLayerFloats, d_fc_w, d_attn_l, d_attn_r, d_bn1_g, d_bn1_b, d_w1, d_b1, d_w2,
+                       d_b2, d_bn2_g, d_bn2_b);
+        const float *h = w.H + row * l, *ft = w.FT + row * l, *g = w.G + row * l, *h1 = w.H1 + row * l, *h3 = w.H3 + row * l;
+        const float *att = w.ATT + (size_t)M * 16 * l, *bn = w.BN + (size_t)l * 8 * 128;
+        // BatchNorm 2 backward (models.py:35): DA = d(layer output) -> DB = d h3
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DA, h3, nullptr, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_bn_bwd_finalize(w.CSP, nb, M, bn2_g, bn + 4 * 128, bn + 5 * 128, d_bn2_g, d_bn2_b, w.COEF, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+          GNNGLS_TRY(gnngls::launch_bn_bwd_apply(w.DA, h3, bn + 4 * 128, w.COEF, w.DB, M, st));
+          GNNGLS_TRY(gnngls::launch_affine_cols(h1, bn + 2 * 128, bn + 3 * 128, w.X2, M, st)); }        // x = BN1(h1), recomputed
+        // feed-forward block backward (models.py:28-33): h3 = x + W2 relu(W1 x + b1) + b2
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);
+          GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, w.X2, w1, w.BIG, M, 512, 128, b1, nullptr, nullptr, nullptr, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DB, w.BIG, M, 128, 512, w.TNP, d_w2, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DB, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, d_b2, nullptr, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d pre = (d h3 * W2) . [relu > 0], in place over the activations
+          GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_MASK, w.DB, w2, w.BIG, M, 512, 128, w.BIG, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.BIG, w.X2, M, 512, 128, w.TNP, d_w1, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.BIG, nullptr, nullptr, M, 512, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 512, 1, d_b1, nullptr, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d x = d pre * W1 + d h3 (skip, models.py:15)
+          GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_ADD, w.BIG, w1, w.DA, M, 128, 512, w.DB, st)); }
+        // BatchNorm 1 backward (models.py:27): DA = d x -> DB = d h1 (= d h through the skip, = d GATConv output)
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DA, h1, nullptr, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_bn_bwd_finalize(w.CSP, nb, M, bn1_g, bn, bn + 128, d_bn1_g, d_bn1_b, w.COEF, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+          GNNGLS_TRY(gnngls::launch_bn_bwd_apply(w.DA, h1, bn, w.COEF, w.DB, M, st)); }
+        // GATConv backward (models.py:23)
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GAT_BWD, st);
+          GNNGLS_TRY(gnngls::launch_gat_bwd_rows(ft, w.DB, g, att, attn_l, attn_r, B, n, w.PART, w.PMS, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
+          GNNGLS_TRY(gnngls::launch_gat_bwd_combine(w.PART, w.PMS, attn_l, attn_r, M, w.DFT, w.DLR, w.DLR + (size_t)M * 8, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_HEADSCALE, ft, w.DLR, w.DLR + (size_t)M * 8, M, 128, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, d_attn_l, d_attn_r, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DFT, h, M, 128, 128, w.TNP, d_fc_w, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d h = d ft * Wfc + d h1 (skip, models.py:15)
+          GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_ADD, w.DFT, fc_w, w.DA, M, 128, 128, w.DB, st)); }
+    }
+    // embedding (models.py:66): h0 = x We^T + be
+    { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
+      for (int d = 0; d < in_dim; ++d) {
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_ROWSCALE, w.DA, feat + d, nullptr, M, 128, in_dim, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, in_dim, g_emb_w + d, d == 0 ? g_emb_b : nullptr, st));
+      } }
+    return GNNGLS_OK;
+}
+
+#undef GNNGLS_TRY
 
 }  // extern "C"
 

@@ -5,7 +5,7 @@
 
 namespace gnngls {
 
-enum { GEMM_EPI_STORE = 0, GEMM_EPI_BIAS_RELU = 1, GEMM_EPI_BIAS_SKIP_BN = 2 };
+enum { GEMM_EPI_STORE = 0, GEMM_EPI_BIAS_RELU = 1, GEMM_EPI_BIAS_SKIP_BN = 2, GEMM_EPI_MASK = 3, GEMM_EPI_ADD = 4 };
 
 size_t gat_rows_lds_bytes(int n);
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st);
@@ -13,6 +13,12 @@ hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, doub
 hipError_t launch_embed(const float *x, const float *W, const float *b, float *h, long M, int in_dim, hipStream_t st);
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
                        const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st);
+// C[M,N] = A[M,K] * W[K,N] (W row-major [K,N]); epi STORE / MASK (C = acc * (aux > 0)) / ADD (C = acc + aux)
+hipError_t launch_gemm_wkn(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *aux,
+                           hipStream_t st);
+hipError_t launch_ffn_fused_pre(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *bn2_s, const float *bn2_b, float *hout,
+                                long M, hipStream_t st);
 hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
                            float *part_ms, hipStream_t st);
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,

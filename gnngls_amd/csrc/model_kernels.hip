@@ -102,15 +102,19 @@ __global__ void embed_kernel(const float *x, const float *W, const float *bias, 
 //   block 256 threads = 4 waves, tile 128x128, wave tile 64x64 (2x2 MFMA tiles), BK = 32
 //   LDS images are k-major ([k][row], row stride 129 floats): fragment reads are conflict-free.
 // ---------------------------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_SKIP_BN = 2 };
+// training-only epilogues (train_kernels.hip): EPI_MASK  C = acc * (skip[row,col] > 0)   (ReLU backward; C may alias skip)
+//                                               EPI_ADD   C = acc + skip[row,col]         (skip-connection backward)
+// WKN: the second operand is given as W[K,N] row-major (C = A * W) instead of W[N,K] (C = A * W^T) -- the data-gradient
+// GEMMs of the backward pass read the forward weights in place, no transposed copies.
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_BIAS_SKIP_BN = 2, EPI_MASK = 3, EPI_ADD = 4 };
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BM + 1;
 
-template <int EPI>
+template <int EPI, bool WKN = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, const float *__restrict__ W,
-                                                       float *__restrict__ C, long M, int N, int K,
+                                                       float *C, long M, int N, int K,
                                                        const float *__restrict__ bias,
-                                                       const float *__restrict__ skip,
+                                                       const float *skip,
                                                        const float *__restrict__ bn_scale,
                                                        const float *__restrict__ bn_shift) {
     __shared__ float As[BK * LDT];
@@ -134,13 +138,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     const bool arow_ok = arow < M;
     const float *aptr = A + (arow_ok ? arow : 0) * (long)K + sk;
     const float *wptr = W + (long)(col0 + srow) * K + sk;
+    // W[K,N] staging map: slot u of the thread covers k = (u*256 + tid) / 32, 4 consecutive columns at ((u*256 + tid) % 32) * 4
+    const int tk = tid >> 5, tc = (tid & 31) * 4;
 
     f32x4 ra[4], rw[4];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             ra[u] = arow_ok ? *reinterpret_cast<const f32x4 *>(aptr + k0 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rw[u] = *reinterpret_cast<const f32x4 *>(wptr + k0 + 4 * u);
+            rw[u] = WKN ? *reinterpret_cast<const f32x4 *>(W + (long)(k0 + 8 * u + tk) * N + col0 + tc)
+                        : *reinterpret_cast<const f32x4 *>(wptr + k0 + 4 * u);
         }
     };
     auto lstore = [&]() {
@@ -149,7 +156,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 As[(sk + 4 * u + c) * LDT + srow] = ra[u][c];
-                Ws[(sk + 4 * u + c) * LDT + srow] = rw[u][c];
+                if (WKN) Ws[(8 * u + tk) * LDT + tc + c] = rw[u][c];
+                else Ws[(sk + 4 * u + c) * LDT + srow] = rw[u][c];
             }
     };
 
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     for (int tb = 0; tb < 2; ++tb) {
         const int col = col0 + wc + tb * 32 + lc;
         float bv = 0.f, sc = 1.f, sh = 0.f;
-        if (EPI != EPI_STORE) bv = bias[col];
+        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SKIP_BN) bv = bias[col];
         if (EPI == EPI_BIAS_SKIP_BN) { sc = bn_scale[col]; sh = bn_shift[col]; }
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta) {
@@ -194,6 +202,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                     v = skip[row * (long)N + col] + v;        // x + y        (models.py:15)
                     v = v * sc + sh;                          // BatchNorm1d eval (models.py:35)
                 }
+                if (EPI == EPI_MASK) v = skip[row * (long)N + col] > 0.f ? v : 0.f;
+                if (EPI == EPI_ADD) v = v + skip[row * (long)N + col];
                 C[row * (long)N + col] = v;
             }
         }
@@ -403,6 +413,9 @@ __device__ __forceinline__ void ffn_gemm2_stage(f32x4 (&accY)[8], const f32x4 (&
     }
 }
 
+// PRE (training forward): the x tile is BN1 applied to an already merged h1 = h + GATConv(h) passed in `hin`
+// (part / part_ms unused); the batch statistics of h1 must be known before BN1 can be applied.
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
                                                            const float *__restrict__ hin,
                                                            const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
@@ -437,24 +450,29 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
             const long m = row0 + row;
             live[u] = m < M;
             const long mc = live[u] ? m : 0;
-            const float *ms0 = part_ms + mc * (2 * kH), *ms1 = part_ms + (M + mc) * (2 * kH);
-            m0[u] = ms0[hd]; s0[u] = ms0[kH + hd]; m1[u] = ms1[hd]; s1[u] = ms1[kH + hd];
-            p0[u] = *reinterpret_cast<const f32x4 *>(part + mc * kD + c);
-            p1[u] = *reinterpret_cast<const f32x4 *>(part + (M + mc) * kD + c);
+            if (!PRE) {
+                const float *ms0 = part_ms + mc * (2 * kH), *ms1 = part_ms + (M + mc) * (2 * kH);
+                m0[u] = ms0[hd]; s0[u] = ms0[kH + hd]; m1[u] = ms1[hd]; s1[u] = ms1[kH + hd];
+                p0[u] = *reinterpret_cast<const f32x4 *>(part + mc * kD + c);
+                p1[u] = *reinterpret_cast<const f32x4 *>(part + (M + mc) * kD + c);
+            }
             hv[u] = *reinterpret_cast<const f32x4 *>(hin + mc * kD + c);
         }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             const int idx = (it0 + u) * 256 + tid;
             const int row = idx >> 5, c = (idx & 31) * 4;
-            const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
-            const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
-            const float inv = 1.f / (s0[u] * a0 + s1[u] * a1);
+            float a0 = 0.f, a1 = 0.f, inv = 0.f;
+            if (!PRE) {
+                const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
+                a0 = __expf(m0[u] - mx); a1 = __expf(m1[u] - mx);
+                inv = 1.f / (s0[u] * a0 + s1[u] * a1);
+            }
             f32x4 o4;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const float g = (p0[u][v] * a0 + p1[u][v] * a1) * inv;
-                const float o = (hv[u][v] + g) * bn1_s[c + v] + bn1_b[c + v];
+                const float g = PRE ? 0.f : (p0[u][v] * a0 + p1[u][v] * a1) * inv;
+                const float o = (PRE ? hv[u][v] : hv[u][v] + g) * bn1_s[c + v] + bn1_b[c + v];
                 o4[v] = live[u] ? o : 0.f;
             }
             *reinterpret_cast<f32x4 *>(Xs + row * LDX + c) = o4;
@@ -590,6 +608,20 @@ hipError_t launch_embed(const float *x, const float *W, const float *b, float *h
     return hipGetLastError();
 }
 
+hipError_t launch_gemm_wkn(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *aux,
+                           hipStream_t st) {
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(N / BN));
+    (void)hipGetLastError();
+    if (epi == EPI_MASK) {
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_MASK, true>), grid, dim3(256), 0, st, A, W, C, M, N, K, nullptr, aux, nullptr, nullptr);
+    } else if (epi == EPI_ADD) {
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_ADD, true>), grid, dim3(256), 0, st, A, W, C, M, N, K, nullptr, aux, nullptr, nullptr);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_STORE, true>), grid, dim3(256), 0, st, A, W, C, M, N, K, nullptr, aux, nullptr, nullptr);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
                        const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st) {
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(N / BN));
@@ -619,11 +651,26 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
     const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW + 896) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, part, part_ms, hin,
+    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, part, part_ms, hin,
+                       bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M);
+    return hipGetLastError();
+}
+
+// training forward: h3 = x + W2*ReLU(W1*x + b1) + b2 with x = h1*bn1_s + bn1_b; `bn2_s`/`bn2_b` are passed as
+// ones/zeros by the caller (BatchNorm 2 needs the batch statistics of h3 first)
+hipError_t launch_ffn_fused_pre(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *bn2_s, const float *bn2_b, float *hout,
+                                long M, hipStream_t st) {
+    const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW + 896) * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, nullptr, nullptr, h1,
                        bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M);
     return hipGetLastError();
 }

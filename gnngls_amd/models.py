@@ -6,6 +6,11 @@ state-dict key layout (so `model.load_state_dict(checkpoint['model_state_dict'])
 packs the parameters once into the fp32 weight image declared in include/gnngls_hip.h and calls
 `gnngls_regret_forward` (hand-written HIP: f32-MFMA node MLPs + LDS-tiled line-graph attention).
 
+In training mode (`model.train()`, scripts/train.py:20-32) `forward` is one autograd node: the HIP training forward
+(`gnngls_regret_train_forward`, BatchNorm on batch statistics, running statistics updated like torch does) whose backward
+is `gnngls_regret_train_backward`; `loss.backward()` / `optimizer.step()` of train.py work unchanged on the module's
+parameters.
+
 The graph argument `G` is a `LineGraph` (this package's stand-in for the DGL graph built at
 datasets.py:56-60); because the line graph of the complete graph K_n has closed-form structure it
 only carries n and the node->TSP-edge map.
@@ -149,6 +154,25 @@ class EdgePropertyPredictionModel(nn.Module):
     def invalidate(self):
         self._packed = None
 
+    def _state_version(self):
+        """Changes whenever a parameter or buffer is written in place (optimizer.step(), running statistics)."""
+        return tuple(t._version for t in itertools.chain(self.parameters(), self.buffers()))
+
+    def train_parameters(self):
+        """Parameters in the order of the raw training image (include/gnngls_hip.h, N4)."""
+        out = [self.embed_layer.weight, self.embed_layer.bias]
+        for layer in self.message_passing_layers:
+            gat = layer.message_passing.module
+            bn1, ff, bn2 = layer.feed_forward[0], layer.feed_forward[1].module, layer.feed_forward[2]
+            if gat.bias is not None:
+                raise NotImplementedError("training with a GATConv bias (DGL >= 0.7 checkpoints) is not supported")
+            out += [gat.fc.weight, gat.attn_l, gat.attn_r, bn1.weight, bn1.bias, ff[0].weight, ff[0].bias,
+                    ff[2].weight, ff[2].bias, bn2.weight, bn2.bias]
+        return out + [self.decision_layer.weight, self.decision_layer.bias]
+
+    def batch_norms(self):
+        return [bn for layer in self.message_passing_layers for bn in (layer.feed_forward[0], layer.feed_forward[2])]
+
     def load_state_dict(self, *args, **kwargs):
         self._packed = None
         return super().load_state_dict(*args, **kwargs)
@@ -160,8 +184,6 @@ class EdgePropertyPredictionModel(nn.Module):
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, G, x):
         """x [B*N, in_dim] fp32 on the GPU, G a LineGraph -> [B*N, 1] fp32 (models.py:65-70)."""
-        if self.training:
-            raise NotImplementedError("training forward/backward is out of scope; call model.eval() (test.py:54)")
         if not x.is_cuda:
             raise _lib.GnnglsHipError("EdgePropertyPredictionModel.forward needs CUDA/HIP tensors (no CPU fallback)")
         n = G.n
@@ -169,15 +191,86 @@ class EdgePropertyPredictionModel(nn.Module):
         x = x.contiguous().float()
         total, in_dim = x.shape
         assert in_dim == self.in_dim and total % N == 0 and total == G.number_of_nodes()
+        if self.training:                                   # train.py:20-32
+            self._check_supported()
+            return _TrainStep.apply(self, x, total // N, n, *self.train_parameters())
         return regret_forward(self, x, total // N, n).reshape(total, 1)
+
+
+class _TrainStep(torch.autograd.Function):
+    """y_pred = model(batch, x) in training mode as ONE autograd node over the HIP training kernels."""
+
+    @staticmethod
+    def forward(ctx, model, x, B, n, *params):
+        L = _lib.load()
+        dev = x.device
+        n_layers = len(model.message_passing_layers)
+        image = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(3, device=dev)]).contiguous()
+        assert image.numel() == L.gnngls_model_packed_floats(model.in_dim, n_layers)
+        N = n * (n - 1) // 2
+        # the workspace holds the activations the backward needs: one per forward call, owned by the autograd node
+        ws = torch.empty(int(L.gnngls_regret_train_workspace_bytes(B, n, n_layers)), dtype=torch.uint8, device=dev)
+        y = torch.empty((B * N, 1), dtype=torch.float32, device=dev)
+        stats = torch.empty((n_layers, 2, 2, EMBED_DIM), dtype=torch.float32, device=dev)
+        bns = model.batch_norms()
+        eps = bns[0].eps if bns else 1e-5
+        _lib.check(L.gnngls_regret_train_forward(_lib.ptr(x), _lib.ptr(image), B, n, model.in_dim, n_layers, eps,
+                                                 _lib.ptr(y), _lib.ptr(stats), _lib.ptr(ws), ctypes.c_int64(ws.numel()),
+                                                 _lib.current_stream()), "regret_train_forward")
+        _update_running_stats(bns, stats.reshape(-1, 2, EMBED_DIM))
+        ctx.model_dims = (B, n, model.in_dim, n_layers)
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(x, image)
+        ctx.ws = ws
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.load()
+        x, image = ctx.saved_tensors
+        B, n, in_dim, n_layers = ctx.model_dims
+        grads = torch.empty_like(image)
+        dy = dy.contiguous().float()
+        _lib.check(L.gnngls_regret_train_backward(_lib.ptr(x), _lib.ptr(image), _lib.ptr(dy), B, n, in_dim, n_layers,
+                                                  _lib.ptr(grads), _lib.ptr(ctx.ws), ctypes.c_int64(ctx.ws.numel()),
+                                                  _lib.current_stream()), "regret_train_backward")
+        ctx.ws = None
+        out, off = [], 0
+        for shape in ctx.shapes:
+            k = shape.numel()
+            out.append(grads[off:off + k].view(shape))
+            off += k
+        return (None, None, None, None, *out)
+
+
+@torch.no_grad()
+def _update_running_stats(bns, stats):
+    """nn.BatchNorm1d's training-mode bookkeeping (models.py:27,35): running <- (1-f)*running + f*batch with the
+    UNBIASED batch variance, f = momentum (or 1/num_batches_tracked when momentum is None)."""
+    tracked = [(bn, stats[k]) for k, bn in enumerate(bns) if bn.track_running_stats and bn.running_mean is not None]
+    if not tracked:
+        return
+    torch._foreach_add_([bn.num_batches_tracked for bn, _ in tracked], 1)
+    momenta = {bn.momentum for bn, _ in tracked}
+    if len(momenta) == 1 and None not in momenta:
+        f = momenta.pop()
+        torch._foreach_lerp_([bn.running_mean for bn, _ in tracked], [s[0] for _, s in tracked], f)
+        torch._foreach_lerp_([bn.running_var for bn, _ in tracked], [s[1] for _, s in tracked], f)
+        return
+    for bn, s in tracked:
+        f = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        bn.running_mean.lerp_(s[0], f)
+        bn.running_var.lerp_(s[1], f)
 
 
 def regret_forward(model, feat, B, n, max_workspace_bytes=48 << 30):
     """feat [B*N, in_dim] (or [B,N]) fp32 cuda -> y [B,N] fp32 cuda via gnngls_regret_forward."""
     L = _lib.load()
     dev = feat.device
-    if model._packed is None or model._packed.device != dev:
+    version = model._state_version()
+    if model._packed is None or model._packed.device != dev or getattr(model, "_packed_version", None) != version:
         model._packed = model.pack_weights(dev)
+        model._packed_version = version
     N = n * (n - 1) // 2
     need = int(L.gnngls_regret_forward_workspace_bytes(B, n))
     ws_bytes = min(need, max(int(L.gnngls_regret_forward_workspace_bytes(1, n)), max_workspace_bytes))

@@ -142,6 +142,25 @@ int64_t gnngls_regret_forward_workspace_bytes(int B, int n);
 int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
                           float *y_out, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- N4: one training step of the same model (scripts/train.py:20-32) -------------------------------------------
+ * model.train(); y_pred = model(batch, x); loss = criterion(y_pred, y); loss.backward() for a dgl.batch of B line graphs
+ * of K_n (train.py:118-121): BatchNorm1d uses the statistics of all B*N rows (models.py:27,35), GATConv is
+ * differentiated through its edge softmax (models.py:23).  The criterion itself (MSELoss / BCEWithLogitsLoss,
+ * train.py:106-112) is elementwise on [B*N] values and stays with the caller: the forward returns y_pred, the backward
+ * takes dy = d loss / d y_pred.
+ *
+ * `params` is the RAW parameter image: the layout of the packed inference image above with the BatchNorm slots holding
+ * gamma / beta instead of the folded scale / shift (gnngls_model_packed_floats floats); `grads` has the same layout.
+ *   forward : feat [B,N,in_dim] -> y_out [B,N]; bn_batch_stats [n_layers][2 (BN1, BN2)][2 (mean, unbiased var)][128]
+ *             is what the caller folds into running_mean / running_var (momentum update, torch semantics).
+ *   backward: must follow a forward on the SAME workspace (activations are kept there); writes every gradient.
+ * n is limited by the LDS tile of the attention backward (n <= 106).  GATConv bias (DGL >= 0.7) is not supported. */
+int64_t gnngls_regret_train_workspace_bytes(int B, int n, int n_layers);
+int gnngls_regret_train_forward(const float *feat, const float *params, int B, int n, int in_dim, int n_layers, float bn_eps,
+                                float *y_out, float *bn_batch_stats, void *workspace, int64_t workspace_bytes, void *stream);
+int gnngls_regret_train_backward(const float *feat, const float *params, const float *dy, int B, int n, int in_dim,
+                                 int n_layers, float *grads, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* get_scaled_features (datasets.py:73-95) for features=[weight] (datasets.py:14-20):
  * feat[b, rank(i<j)] = MinMaxScaler.transform(float32(D[b,i,j])) with sklearn's fp32 arithmetic
  * (x*scale_ rounded to fp32, + min_ rounded to fp32). */
@@ -166,7 +185,9 @@ int gnngls_debug_set_stamp_buffer(void *device_buffer);
 enum {
     GNNGLS_PROF_PACK = 0, GNNGLS_PROF_EMBED, GNNGLS_PROF_GEMM_FC, GNNGLS_PROF_GAT_ROWS, GNNGLS_PROF_GAT_COMBINE,
     GNNGLS_PROF_GEMM_FFN1, GNNGLS_PROF_GEMM_FFN2, GNNGLS_PROF_DECISION, GNNGLS_PROF_UNPACK,
-    GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_FFN_FUSED, GNNGLS_PROF_KINDS
+    GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_FFN_FUSED,
+    GNNGLS_PROF_TRAIN_COLSUM, GNNGLS_PROF_TRAIN_ELEMENTWISE, GNNGLS_PROF_TRAIN_GEMM_BWD, GNNGLS_PROF_TRAIN_GEMM_TN,
+    GNNGLS_PROF_TRAIN_GAT_BWD, GNNGLS_PROF_KINDS
 };
 int gnngls_profile_enable(int on);
 int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);

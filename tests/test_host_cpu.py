@@ -82,8 +82,13 @@ def test_line_graph_and_state_dict_layout():
     assert torch.equal(packed[-132:-4], sd_o["decision_layer.weight"].reshape(-1))
     with pytest.raises(NotImplementedError):
         EdgePropertyPredictionModel(1, 64, 1, 3, n_heads=4).pack_weights("cpu")
-    with pytest.raises(NotImplementedError):
-        model.train()(G, torch.zeros(45, 1))
+    from gnngls_amd import _lib
+    for mode in (model.train(), model.eval()):          # no CPU path in either mode
+        with pytest.raises(_lib.GnnglsHipError):
+            mode(G, torch.zeros(45, 1))
+    # order of the raw training image (include/gnngls_hip.h, N4) = order of the packed inference image
+    tp = model.train_parameters()
+    assert sum(p.numel() for p in tp) + 3 == packed.numel() and tp[2] is model.message_passing_layers[0].message_passing.module.fc.weight
 
 
 def test_dataset_surface(tmp_path):
