@@ -6,7 +6,7 @@
 namespace gnngls {
 
 enum { CS_SUM_SQ = 0, CS_SUM_PROD = 1, CS_ROWSCALE = 2, CS_HEADSCALE = 3 };
-constexpr int kColsumMaxBlocks = 1024;     // partial buffer: kColsumMaxBlocks * 2 * 512 doubles
+constexpr int kColsumMaxBlocks = 512;     // partial buffer: kColsumMaxBlocks * 2 * 512 doubles
 constexpr int kGemmTnMaxChunks = 256;      // partial buffer: kGemmTnMaxChunks * 128 * 512 floats
 
 int colsum_blocks(long M, int C);

@@ -93,19 +93,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     }
 }
 
-__device__ __forceinline__ double sum_partials(const double *partial, int nblocks, int k, int C, int c) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[((long)b * 2 + k) * C + c];
-    return s;
+// Final stage: 1024 threads, thread (c, part) sums every (1024/C)-th partial of column c (independent loads in flight),
+// the parts meet in LDS; returns the two column sums to the threads with part == 0 (tid < C).
+__device__ __forceinline__ void sum_partials(const double *__restrict__ partial, int nblocks, int C, double *red,
+                                             double &s0, double &s1) {
+    const int tid = threadIdx.x, c = tid % C, part = tid / C, P = 1024 / C;
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+    for (int b = part; b < nblocks; b += P) {
+        a0 += partial[((long)b * 2) * C + c];
+        a1 += partial[((long)b * 2 + 1) * C + c];
+    }
+    red[tid] = a0; red[1024 + tid] = a1;
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    if (part == 0)
+        for (int q = 0; q < P; ++q) { s0 += red[q * C + c]; s1 += red[1024 + q * C + c]; }
 }
 
 // out0[c] = sum f0 (if out0), out1[c] = sum f1 (if out1), rounded to fp32 -- plain gradient vectors
 // (out0 with element stride `ostride`: a column of the [128, in_dim] embedding weight)
-__global__ void colsum_store_kernel(const double *partial, int nblocks, int C, int ostride, float *out0, float *out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void colsum_store_kernel(const double *partial, int nblocks, int C, int ostride, float *out0,
+                                                            float *out1) {
+    __shared__ double red[2048];
+    double s0, s1;
+    sum_partials(partial, nblocks, C, red, s0, s1);
+    const int c = threadIdx.x;
     if (c >= C) return;
-    if (out0) out0[(long)c * ostride] = (float)sum_partials(partial, nblocks, 0, C, c);
-    if (out1) out1[c] = (float)sum_partials(partial, nblocks, 1, C, c);
+    if (out0) out0[(long)c * ostride] = (float)s0;
+    if (out1) out1[c] = (float)s1;
 }
 
 // out[0] = sum_m v[m] in fp64 (decision bias gradient, out_dim = 1); one workgroup
@@ -125,12 +141,17 @@ __global__ __launch_bounds__(1024) void sum_vector_kernel(const float *__restric
 // BatchNorm1d training forward (models.py:27,35; torch: biased variance for the normalisation, unbiased for the running
 // estimate): scale = gamma * invstd, shift = beta - mean * scale; saves mean / invstd for the backward and hands the
 // batch mean / unbiased variance to the caller (running-statistics update)
-__global__ void bn_stats_finalize_kernel(const double *partial, int nblocks, long M, const float *gamma, const float *beta,
-                                         float eps, float *scale, float *shift, float *mean_out, float *invstd_out,
-                                         float *batch_mean, float *batch_var_unbiased) {
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double *partial, int nblocks, long M, const float *gamma,
+                                                                 const float *beta, float eps, float *scale, float *shift,
+                                                                 float *mean_out, float *invstd_out, float *batch_mean,
+                                                                 float *batch_var_unbiased) {
+    __shared__ double red[2048];
+    double s0, s1;
+    sum_partials(partial, nblocks, kD, red, s0, s1);
     const int c = threadIdx.x;
-    const double mean = sum_partials(partial, nblocks, 0, kD, c) / (double)M;
-    double var = sum_partials(partial, nblocks, 1, kD, c) / (double)M - mean * mean;
+    if (c >= kD) return;
+    const double mean = s0 / (double)M;
+    double var = s1 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const double sc = (double)gamma[c] * invstd;
@@ -144,11 +165,14 @@ __global__ void bn_stats_finalize_kernel(const double *partial, int nblocks, lon
 
 // BatchNorm backward: dgamma = invstd * (sum dy*x - mean * sum dy), dbeta = sum dy,
 //   dx = A*dy + Bc*(x - mean) + Cc   with A = gamma*invstd, Bc = -A*invstd*dgamma/M, Cc = -A*dbeta/M
-__global__ void bn_bwd_finalize_kernel(const double *partial, int nblocks, long M, const float *gamma, const float *mean,
-                                       const float *invstd, float *dgamma, float *dbeta, float *coef /*[3][128]*/) {
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double *partial, int nblocks, long M, const float *gamma,
+                                                               const float *mean, const float *invstd, float *dgamma,
+                                                               float *dbeta, float *coef /*[3][128]*/) {
+    __shared__ double red[2048];
+    double sdy, sdyx;
+    sum_partials(partial, nblocks, kD, red, sdy, sdyx);
     const int c = threadIdx.x;
-    const double sdy = sum_partials(partial, nblocks, 0, kD, c);
-    const double sdyx = sum_partials(partial, nblocks, 1, kD, c);
+    if (c >= kD) return;
     const double is = (double)invstd[c], mu = (double)mean[c];
     const double dg = is * (sdyx - mu * sdy);
     dgamma[c] = (float)dg;
@@ -244,6 +268,8 @@ __global__ void gat_combine_train_kernel(const float *__restrict__ part, const f
 constexpr int LDG = 132;   // LDS row stride (floats): a ds_read_b128 of 16 consecutive rows at one column offset touches
                            // 16 disjoint groups of 4 banks; 4 rows 4 apart (MFMA B fragment) land on disjoint 16-bank groups
 
+constexpr int kGatBwdThreads = 512;   // 8 waves: the one workgroup a CU holds (LDS) keeps two waves per SIMD in flight
+
 __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over the 16-lane DPP row; lane 15 holds the total
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
@@ -252,7 +278,7 @@ __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over
     return v;
 }
 
-__global__ __launch_bounds__(256) void gat_bwd_rows_kernel(const float *__restrict__ ft, const float *__restrict__ dout,
+__global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const float *__restrict__ ft, const float *__restrict__ dout,
                                                            const float *__restrict__ gout, const float *__restrict__ att,
                                                            const float *__restrict__ attn_l, const float *__restrict__ attn_r,
                                                            int n, float *__restrict__ P, float *__restrict__ dlr) {
@@ -271,19 +297,19 @@ __global__ __launch_bounds__(256) void gat_bwd_rows_kernel(const float *__restri
     const size_t Mtot = (size_t)gridDim.x / n * N;                // B*N rows per side
 
     const size_t base = (size_t)b * N;
-    for (int s = tid; s < ns; s += 256) {
+    for (int s = tid; s < ns; s += kGatBwdThreads) {
         const int k = s < u ? s : s + 1;
         nodeS[s] = k < u ? tri_index(k, u, n) : tri_index(u, k, n);
     }
     __syncthreads();
-    for (int q = tid; q < ns * (kD / 4); q += 256) {
+    for (int q = tid; q < ns * (kD / 4); q += kGatBwdThreads) {
         const int s = q >> 5, c = (q & 31) * 4;
         const size_t row = (base + nodeS[s]) * kD + c;
         *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(ft + row);
         *reinterpret_cast<f32x4 *>(dgS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(dout + row);
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += 256) {
+    for (int q = tid; q < ns * kH; q += kGatBwdThreads) {
         const int s = q >> 3, h = q & 7;
         const float *f = ftS + (size_t)s * LDG + h * kF;
         const float *d = dgS + (size_t)s * LDG + h * kF;
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256) void gat_bwd_rows_kernel(const float *__restri
 
     const int jl = lane & 15, q4 = lane >> 4;
     float *Pb = P;
-    for (int unit = wave; unit < nt * kH; unit += 4) {
+    for (int unit = wave; unit < nt * kH; unit += kGatBwdThreads / 64) {
         const int st = unit >> 3, h = unit & 7;
         const int j = st * 16 + jl, jc = j < ns ? j : ns - 1;
         const float el_j = elS[jc * kH + h];
@@ -360,7 +386,7 @@ __global__ __launch_bounds__(256) void gat_bwd_rows_kernel(const float *__restri
         }
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += 256) {
+    for (int q = tid; q < ns * kH; q += kGatBwdThreads) {
         const int i = q >> 3, h = q & 7;
         float s = 0.f;
         for (int st = 0; st < nt; ++st) s += derP[((size_t)st * nsp + i) * kH + h];
@@ -499,7 +525,7 @@ hipError_t launch_colsum(int mode, const float *X, const float *Y, const float *
 hipError_t launch_colsum_store(const double *partial, int nblocks, int C, int ostride, float *out0, float *out1,
                                hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(colsum_store_kernel, dim3((C + 127) / 128), dim3(128), 0, st, partial, nblocks, C, ostride, out0, out1);
+    hipLaunchKernelGGL(colsum_store_kernel, dim3(1), dim3(1024), 0, st, partial, nblocks, C, ostride, out0, out1);
     return hipGetLastError();
 }
 
@@ -513,7 +539,7 @@ hipError_t launch_bn_stats_finalize(const double *partial, int nblocks, long M, 
                                     float eps, float *scale, float *shift, float *mean, float *invstd, float *batch_mean,
                                     float *batch_var, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(kD), 0, st, partial, nblocks, M, gamma, beta, eps, scale, shift,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblocks, M, gamma, beta, eps, scale, shift,
                        mean, invstd, batch_mean, batch_var);
     return hipGetLastError();
 }
@@ -521,7 +547,7 @@ hipError_t launch_bn_stats_finalize(const double *partial, int nblocks, long M, 
 hipError_t launch_bn_bwd_finalize(const double *partial, int nblocks, long M, const float *gamma, const float *mean,
                                   const float *invstd, float *dgamma, float *dbeta, float *coef, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(kD), 0, st, partial, nblocks, M, gamma, mean, invstd, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nblocks, M, gamma, mean, invstd, dgamma,
                        dbeta, coef);
     return hipGetLastError();
 }
@@ -566,7 +592,7 @@ hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_bwd_rows_kernel, dim3((unsigned)(B * n)), dim3(256), lds, st, ft, dout, gout, att, attn_l, attn_r, n,
+    hipLaunchKernelGGL(gat_bwd_rows_kernel, dim3((unsigned)(B * n)), dim3(kGatBwdThreads), lds, st, ft, dout, gout, att, attn_l, attn_r, n,
                        P, dlr);
     return hipGetLastError();
 }

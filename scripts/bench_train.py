@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Training-step throughput of the HIP path (the step of scripts/train.py:20-32: forward in training
+mode, MSELoss, backward, Adam) on a synthetic dgl.batch-shaped batch.  Prints one JSON line.
+
+    python scripts/bench_train.py [--n 100] [--batch 32] [--steps 20] [--warmup 3]
+
+FLOP model per instance and layer (N = n(n-1)/2 line-graph nodes, E = N * 2(n-2) arcs):
+    forward  : fc 2*N*128^2 + attention E*304 + MLP 4*N*128*512
+    backward : data gradients (fc 2*N*128^2, MLP 4*N*128*512 + the recomputed first MLP GEMM 2*N*128*512),
+               weight gradients (fc 2*N*128^2, MLP 4*N*128*512), attention backward E*(2*16 + 2*16 + 12)*8/8 ~ E*608
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnngls_amd import _lib, models  # noqa: E402
+
+
+def flops_per_instance(n, layers=8):
+    N = n * (n - 1) // 2
+    E = N * 2 * (n - 2)
+    fc, mlp = 2 * N * 128 * 128, 4 * N * 128 * 512
+    fwd = fc + E * 304 + mlp
+    bwd = (fc + mlp + mlp // 2) + (fc + mlp) + E * 608
+    return layers * fwd, layers * bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-optimizer", action="store_true")
+    args = ap.parse_args()
+    n, B = args.n, args.batch
+    N = n * (n - 1) // 2
+    torch.manual_seed(0)
+    model = models.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)                         # train.py:104
+    crit = torch.nn.MSELoss()                                                   # train.py:108
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32)).cuda()
+    G = models.LineGraph(n, batch=B).to("cuda")
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(G, x), y)
+        loss.backward()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    fwd, bwd = flops_per_instance(n)
+    ms = dt / args.steps * 1e3
+    kern = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in prof.items() if v[1]}
+    out = {"metric": "training steps/sec (forward+backward+Adam)", "value": args.steps / dt, "unit": "steps/s",
+           "instances_per_s": B * args.steps / dt, "ms_per_step": ms, "n": n, "batch": B, "steps": args.steps,
+           "warmup": args.warmup, "dtype": "f32", "data": "synthetic", "loss": float(loss.item()),
+           "model_tflops": (fwd + bwd) * B / (ms * 1e-3) / 1e12,
+           "kernel_ms_per_step": sum(v["ms_per_step"] for v in kern.values()), "kernels": kern,
+           "workspace_gib": _lib.load().gnngls_regret_train_workspace_bytes(B, n, 8) / 2 ** 30}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
