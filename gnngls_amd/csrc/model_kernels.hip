@@ -191,6 +191,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
         if (EPI == EPI_BIAS_SKIP_BN) { sc = bn_scale[col]; sh = bn_shift[col]; }
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta) {
+            // (C may alias `skip` for EPI_MASK, so neither is __restrict__: fetch the 16 auxiliary values of the tile
+            // before its first store, otherwise every load waits for the previous store)
+            float auxv[16];
+            if (EPI == EPI_MASK || EPI == EPI_ADD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = row0 + wr + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    auxv[r] = row < M ? skip[row * (long)N + col] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long row = row0 + wr + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                     v = skip[row * (long)N + col] + v;        // x + y        (models.py:15)
                     v = v * sc + sh;                          // BatchNorm1d eval (models.py:35)
                 }
-                if (EPI == EPI_MASK) v = skip[row * (long)N + col] > 0.f ? v : 0.f;
-                if (EPI == EPI_ADD) v = v + skip[row * (long)N + col];
+                if (EPI == EPI_MASK) v = auxv[r] > 0.f ? v : 0.f;
+                if (EPI == EPI_ADD) v = v + auxv[r];
                 C[row * (long)N + col] = v;
             }
         }

@@ -268,7 +268,8 @@ __global__ void gat_combine_train_kernel(const float *__restrict__ part, const f
 constexpr int LDG = 132;   // LDS row stride (floats): a ds_read_b128 of 16 consecutive rows at one column offset touches
                            // 16 disjoint groups of 4 banks; 4 rows 4 apart (MFMA B fragment) land on disjoint 16-bank groups
 
-constexpr int kGatBwdThreads = 512;   // 8 waves: the one workgroup a CU holds (LDS) keeps two waves per SIMD in flight
+constexpr int kGatBwdThreads = 512;   // 8 waves = one per attention head
+constexpr int kGatBwdMaxTiles = 9;    // 16-node tiles per row: n - 1 <= 144 (the LDS tile limits n to 135 anyway)
 
 __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over the 16-lane DPP row; lane 15 holds the total
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
@@ -278,21 +279,24 @@ __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over
     return v;
 }
 
+// Wave h owns head h.  Outer loop: destination tiles dt (dOut fragments, softmax statistics and the B fragments of the
+// second product are fetched once per tile); inner loop: source tiles st, whose P / del accumulators stay in registers
+// for the whole kernel (kGatBwdMaxTiles x 5 VGPRs), while der of the current destination tile accumulates across st and
+// is reduced over the 16 source lanes once per tile.
 __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const float *__restrict__ ft, const float *__restrict__ dout,
-                                                           const float *__restrict__ gout, const float *__restrict__ att,
-                                                           const float *__restrict__ attn_l, const float *__restrict__ attn_r,
-                                                           int n, float *__restrict__ P, float *__restrict__ dlr) {
+                                                                      const float *__restrict__ gout, const float *__restrict__ att,
+                                                                      const float *__restrict__ attn_l, const float *__restrict__ attn_r,
+                                                                      int n, float *__restrict__ P, float *__restrict__ dlr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int N = n * (n - 1) / 2;
-    const int ns = n - 1, nt = (ns + 15) >> 4, nsp = nt * 16;
+    const int ns = n - 1, nt = (ns + 15) >> 4;
     const int b = blockIdx.x / n, u = blockIdx.x % n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
     float *ftS = reinterpret_cast<float *>(smem);                 // [ns][LDG]
     float *dgS = ftS + (size_t)ns * LDG;                          // [ns][LDG]
     float *elS = dgS + (size_t)ns * LDG;                          // [ns][8]
     f32x4 *stS = reinterpret_cast<f32x4 *>(elS + (size_t)ns * kH);  // [ns][8] (er, -max*log2e, 1/Z, c)
-    float *derP = reinterpret_cast<float *>(stS + (size_t)ns * kH);  // [nt][nsp][8]
-    int *nodeS = reinterpret_cast<int *>(derP + (size_t)nt * nsp * kH);   // [ns]
+    int *nodeS = reinterpret_cast<int *>(stS + (size_t)ns * kH);  // [ns] line-graph node of slot s
     const float kLog2e = 1.4426950408889634f;
     const size_t Mtot = (size_t)gridDim.x / n * N;                // B*N rows per side
 
@@ -310,88 +314,96 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
     }
     __syncthreads();
     for (int q = tid; q < ns * kH; q += kGatBwdThreads) {
-        const int s = q >> 3, h = q & 7;
-        const float *f = ftS + (size_t)s * LDG + h * kF;
-        const float *d = dgS + (size_t)s * LDG + h * kF;
-        const float *go = gout + (base + nodeS[s]) * kD + h * kF;
+        const int s = q >> 3, hh = q & 7;
+        const float *f = ftS + (size_t)s * LDG + hh * kF;
+        const float *d = dgS + (size_t)s * LDG + hh * kF;
+        const float *go = gout + (base + nodeS[s]) * kD + hh * kF;
         float l = 0.f, r = 0.f, c = 0.f;
 #pragma unroll
         for (int v = 0; v < kF; ++v) {
-            l = fmaf(f[v], attn_l[h * kF + v], l);
-            r = fmaf(f[v], attn_r[h * kF + v], r);
+            l = fmaf(f[v], attn_l[hh * kF + v], l);
+            r = fmaf(f[v], attn_r[hh * kF + v], r);
             c = fmaf(d[v], go[v], c);
         }
         const float *a = att + (base + nodeS[s]) * (2 * kH);
         elS[q] = l;
-        stS[q] = f32x4{r, -a[h] * kLog2e, a[kH + h], c};
+        stS[q] = f32x4{r, -a[hh] * kLog2e, a[kH + hh], c};
     }
     __syncthreads();
 
     const int jl = lane & 15, q4 = lane >> 4;
-    float *Pb = P;
-    for (int unit = wave; unit < nt * kH; unit += kGatBwdThreads / 64) {
-        const int st = unit >> 3, h = unit & 7;
-        const int j = st * 16 + jl, jc = j < ns ? j : ns - 1;
-        const float el_j = elS[jc * kH + h];
-        // B operand of T = dOut * ft^T: lane (jl, q4) supplies ft[j][16h + 4*q4 + ks], ks = 0..3 (one ds_read_b128)
-        const f32x4 bft = *reinterpret_cast<const f32x4 *>(ftS + (size_t)jc * LDG + h * kF + 4 * q4);
-        f32x4 accP = f32x4{0.f, 0.f, 0.f, 0.f};
-        float del = 0.f;
-        for (int dt = 0; dt < nt; ++dt) {
-            const int ia = dt * 16 + jl, iac = ia < ns ? ia : ns - 1;
-            const f32x4 adg = *reinterpret_cast<const f32x4 *>(dgS + (size_t)iac * LDG + h * kF + 4 * q4);
-            f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
+    // output row of slot s with the side folded in: slot s is node {u,k}, k = s < u ? s : s+1; side 0 iff u < k iff u <= s
+    auto out_row = [&](int s) -> size_t { return ((u <= s) ? 0 : Mtot) + base + nodeS[s]; };
+    f32x4 accP[kGatBwdMaxTiles];
+    float del[kGatBwdMaxTiles];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) T = __builtin_amdgcn_mfma_f32_16x16x4f32(adg[ks], bft[ks], T, 0, 0, 0);
-            // T[r] = t_ij for destination i = 16*dt + 4*q4 + r, source j = 16*st + jl
-            float av[4], dsv[4];
-            float bdg[4];
+    for (int st = 0; st < kGatBwdMaxTiles; ++st) { accP[st] = f32x4{0.f, 0.f, 0.f, 0.f}; del[st] = 0.f; }
+
+    for (int dt = 0; dt < nt; ++dt) {
+        const int ia = dt * 16 + jl, iac = ia < ns ? ia : ns - 1;
+        // A operand of T = dOut * ft^T: lane (jl, q4) supplies dOut[i = 16dt + jl][16h + 4*q4 + ks] (one ds_read_b128)
+        const f32x4 adg = *reinterpret_cast<const f32x4 *>(dgS + (size_t)iac * LDG + h * kF + 4 * q4);
+        f32x4 sv[4];
+        float bdg[4], der[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = dt * 16 + 4 * q4 + r, ic = i < ns ? i : ns - 1;
-                const f32x4 sv = stS[ic * kH + h];
-                bdg[r] = dgS[(size_t)ic * LDG + h * kF + jl];
-                const float x = el_j + sv[0];
-                const float lx = fmaxf(x, kSlope * x);
-                float a = __builtin_amdgcn_exp2f(fmaf(lx, kLog2e, sv[1])) * sv[2];
-                const bool live = (i < ns) && (j < ns) && (i != j);
-                a = live ? a : 0.f;
-                const float ds = a * (T[r] - sv[3]) * (x > 0.f ? 1.f : kSlope);
-                av[r] = a; dsv[r] = ds;
-                del += ds;
-            }
-            // P[j][:] += sum_i a_ij dOut_i[:]: the T accumulator layout (row = 4*q4 + r, col = jl) is the A-operand
-            // layout of step r (row = jl, k = q4) of a^T * dOut
-#pragma unroll
-            for (int r = 0; r < 4; ++r) accP = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bdg[r], accP, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float rs = row16_sum(dsv[r]);
-                if (jl == 15) derP[((size_t)st * nsp + dt * 16 + 4 * q4 + r) * kH + h] = rs;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int i = dt * 16 + 4 * q4 + r, ic = i < ns ? i : ns - 1;
+            sv[r] = stS[ic * kH + h];
+            bdg[r] = dgS[(size_t)ic * LDG + h * kF + jl];
+            der[r] = 0.f;
         }
-        del += __shfl_xor(del, 16, 64);
-        del += __shfl_xor(del, 32, 64);
-        if (q4 == 0 && j < ns) {
-            const int k = j < u ? j : j + 1;
-            dlr[((u < k ? 0 : Mtot) + base + nodeS[j]) * (2 * kH) + h] = del;
+#pragma unroll
+        for (int st = 0; st < kGatBwdMaxTiles; ++st) {
+            if (st < nt) {
+                const int j = st * 16 + jl, jc = j < ns ? j : ns - 1;
+                const float el_j = elS[jc * kH + h];
+                // B operand: lane (jl, q4) supplies ft[j][16h + 4*q4 + ks]
+                const f32x4 bft = *reinterpret_cast<const f32x4 *>(ftS + (size_t)jc * LDG + h * kF + 4 * q4);
+                f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) T = __builtin_amdgcn_mfma_f32_16x16x4f32(adg[ks], bft[ks], T, 0, 0, 0);
+                // T[r] = t_ij for destination i = 16*dt + 4*q4 + r, source j = 16*st + jl
+                float av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = dt * 16 + 4 * q4 + r;
+                    const float x = el_j + sv[r][0];
+                    const float lx = fmaxf(x, kSlope * x);
+                    float a = __builtin_amdgcn_exp2f(fmaf(lx, kLog2e, sv[r][1])) * sv[r][2];
+                    const bool live = (i < ns) && (j < ns) && (i != j);
+                    a = live ? a : 0.f;
+                    const float ds = a * (T[r] - sv[r][3]) * (x > 0.f ? 1.f : kSlope);
+                    av[r] = a;
+                    del[st] += ds;
+                    der[r] += ds;
+                }
+                // P[j][:] += sum_i a_ij dOut_i[:]: the T accumulator layout (row = 4*q4 + r, col = jl) is the A-operand
+                // layout of step r (row = jl, k = q4) of a^T * dOut
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accP[st] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bdg[r], accP[st], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int jr = st * 16 + 4 * q4 + r;
-            if (jr < ns) {
-                const int k = jr < u ? jr : jr + 1;
-                Pb[((u < k ? 0 : Mtot) + base + nodeS[jr]) * kD + h * kF + jl] = accP[r];
-            }
+            const float rs = row16_sum(der[r]);
+            const int i = dt * 16 + 4 * q4 + r;
+            if (jl == 15 && i < ns) dlr[out_row(i) * (2 * kH) + kH + h] = rs;
         }
     }
-    __syncthreads();
-    for (int q = tid; q < ns * kH; q += kGatBwdThreads) {
-        const int i = q >> 3, h = q & 7;
-        float s = 0.f;
-        for (int st = 0; st < nt; ++st) s += derP[((size_t)st * nsp + i) * kH + h];
-        const int k = i < u ? i : i + 1;
-        dlr[((u < k ? 0 : Mtot) + base + nodeS[i]) * (2 * kH) + kH + h] = s;
+#pragma unroll
+    for (int st = 0; st < kGatBwdMaxTiles; ++st) {
+        if (st < nt) {
+            float d = del[st];
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            const int j = st * 16 + jl;
+            if (q4 == 0 && j < ns) dlr[out_row(j) * (2 * kH) + h] = d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jr = st * 16 + 4 * q4 + r;
+                if (jr < ns) P[out_row(jr) * kD + h * kF + jl] = accP[st][r];
+            }
+        }
     }
 }
 
@@ -492,12 +504,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
             }
 }
 
-__global__ void gemm_tn_reduce_kernel(const float *__restrict__ partial, int chunks, long E, float *__restrict__ out) {
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int k = 0; k < chunks; ++k) s += (double)partial[(size_t)k * E + e];
-        out[e] = (float)s;
+// 256 threads = 64 outputs x 4 chunk groups (4x the loads in flight of a one-thread-per-output sum); the groups meet in LDS
+// in fixed order
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ partial, int chunks, long E,
+                                                             float *__restrict__ out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x, el = tid & 63, part = tid >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
+    double s = 0.0;
+    if (e < E) {
+#pragma unroll 8
+        for (int k = part; k < chunks; k += 4) s += (double)partial[(size_t)k * E + e];
     }
+    red[tid] = s;
+    __syncthreads();
+    if (part == 0 && e < E) out[e] = (float)(((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,7 +603,8 @@ hipError_t launch_gat_combine_train(const float *part, const float *part_ms, con
 
 size_t gat_bwd_lds_bytes(int n) {
     const size_t ns = (size_t)n - 1, nt = (ns + 15) / 16, nsp = nt * 16;
-    return 2 * ns * LDG * 4 + ns * kH * 4 + ns * kH * 16 + nt * nsp * kH * 4 + ns * 4 + 16;
+    (void)nt; (void)nsp;
+    return 2 * ns * LDG * 4 + ns * kH * 4 + ns * kH * 16 + ns * 4 + 16;
 }
 
 hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *gout, const float *att, const float *attn_l,
@@ -618,7 +640,7 @@ hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long E = (long)N1 * N2;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(grid_cap((E + 255) / 256, 1024)), dim3(256), 0, st, partial, chunks, E, out);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, partial, chunks, E, out);
     return hipGetLastError();
 }
 

@@ -29,3 +29,7 @@ for k, r in g64.items():
     eh = (grads[k].double() - r).abs().max().item()
     e3 = (g32[k].double() - r).abs().max().item()
     print(f"{k:62s} max {m:.2e} hip {eh:.2e} ({eh / max(m, 1e-30):.1e}) fp32 {e3:.2e} ({e3 / max(m, 1e-30):.1e}) ratio {eh / max(e3, 1e-30):.1f}")
+rh = [(grads[k].double() - r).abs().max().item() / r.abs().max().item() for k, r in g64.items() if r.abs().max().item() > 1e-9]
+r3 = [(g32[k].double() - r).abs().max().item() / r.abs().max().item() for k, r in g64.items() if r.abs().max().item() > 1e-9]
+print("SUMMARY n=%d B=%d  hip: median rel %.2e worst %.2e   fp32 oracle: median rel %.2e worst %.2e" %
+      (n, B, np.median(rh), max(rh), np.median(r3), max(r3)))

@@ -11,7 +11,7 @@ the tensor's largest entry (scripts/probe_train_err.py prints the table; a plain
 oracle evaluated in fp64 and must satisfy, with rel = max|err| / max|g|,
     err <= 3 x (error of the fp32 oracle on the same tensor) + 2e-5 * max|g| + 1e-7 * (largest gradient entry),  or
     rel <= 3 x (worst rel of the fp32 oracle over all tensors)            (a kink flip somewhere else than the oracle's)
-and over all tensors the median rel must stay below 1e-4 and the worst below 5e-3.
+and over all tensors the median / worst rel must stay below max(1e-4, 1.5 x fp32 oracle's) / max(5e-3, 1.5 x fp32 oracle's).
 """
 import copy
 import os
@@ -80,7 +80,7 @@ def test_train_step_golden(n):
             assert np.array_equal(b.numpy(), g["buf/" + k]), k          # num_batches_tracked
 
 
-@pytest.mark.parametrize("n,B", [(3, 5), (4, 3), (6, 2), (17, 2), (33, 2), (50, 1), (64, 2)])
+@pytest.mark.parametrize("n,B", [(3, 5), (4, 3), (6, 2), (17, 2), (33, 2), (50, 1), (64, 2), (100, 1), (120, 1)])
 def test_train_step_vs_oracle(n, B):
     from oracle import model_oracle as mo
     model, oracle = make_models(4321, 77)
@@ -103,7 +103,7 @@ def test_train_step_vs_oracle(n, B):
     gmax = max(v.abs().max().item() for v in g64.values())
     live = [k for k, v in g64.items() if v.abs().max().item() > 1e-9 * gmax]     # (b2 feeds a BatchNorm: exact zero gradient)
     rel32 = max((g32[k].double() - g64[k]).abs().max().item() / g64[k].abs().max().item() for k in live)
-    rels = []
+    rels, rels32 = [], []
     for k, ref64 in g64.items():
         m = ref64.abs().max().item()
         e_hip = (grads[k].double() - ref64).abs().max().item()
@@ -111,9 +111,11 @@ def test_train_step_vs_oracle(n, B):
         bound = 3 * e_32 + 2e-5 * m + 1e-7 * gmax
         if k in live:
             rels.append(e_hip / m)
+            rels32.append(e_32 / m)
         assert e_hip <= bound or (k in live and e_hip / m <= 3 * rel32), \
             f"{k}: err {e_hip:.3e} > bound {bound:.3e} (fp32 oracle err {e_32:.3e}, worst fp32 rel {rel32:.1e})"
-    assert np.median(rels) <= 1e-4 and max(rels) <= 5e-3, (np.median(rels), max(rels))
+    assert np.median(rels) <= max(1e-4, 1.5 * np.median(rels32)), (np.median(rels), np.median(rels32))
+    assert max(rels) <= max(5e-3, 1.5 * max(rels32)), (max(rels), max(rels32))
     # running statistics after the step (models.py:27,35: momentum 0.1, unbiased batch variance)
     for k, ref64 in b64.items():
         if ref64.dtype.is_floating_point:
@@ -186,7 +188,7 @@ def test_training_rejects_unsupported_sizes():
     from gnngls_amd.models import LineGraph
     model, _ = make_models(4321, 77)
     model.train()
-    n = 120                                     # attention-backward tile needs more than 160 KiB of LDS
+    n = 140                                     # attention-backward tile needs more than 160 KiB of LDS
     x = torch.zeros((n * (n - 1) // 2, 1), device="cuda")
     with pytest.raises(_lib.GnnglsHipError):
         model(LineGraph(n).to("cuda"), x)
