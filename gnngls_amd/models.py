@@ -55,6 +55,18 @@ class LineGraph:
         return g
 
 
+def batch(graphs):
+    """dgl.batch (train.py:118-121, the DataLoader's collate_fn) for LineGraphs of one size: the disjoint union is again
+    a LineGraph (batch = total instance count); every ndata entry is concatenated along the node axis."""
+    graphs = list(graphs)
+    if not graphs or any(g.n != graphs[0].n for g in graphs):
+        raise ValueError("batch() needs a non-empty list of line graphs of one instance size (homogeneous dataset)")
+    out = LineGraph.__new__(LineGraph)
+    out.n, out.batch, out.device = graphs[0].n, sum(g.batch for g in graphs), graphs[0].device
+    out.ndata = {k: torch.cat([g.ndata[k] for g in graphs]) for k in graphs[0].ndata}
+    return out
+
+
 class SkipConnection(nn.Module):
     """models.py:5-15 (parameter container; the sum x + y is fused into the HIP epilogues)."""
 

@@ -192,3 +192,62 @@ def test_training_rejects_unsupported_sizes():
     x = torch.zeros((n * (n - 1) // 2, 1), device="cuda")
     with pytest.raises(_lib.GnnglsHipError):
         model(LineGraph(n).to("cuda"), x)
+
+
+def test_train_cli_end_to_end(tmp_path):
+    """scripts/train.py with the reference's arguments on a tiny synthetic dataset: the loss goes down, the checkpoints
+    and params.json appear with the reference's keys, and scripts/test.py's loader accepts the result."""
+    import itertools
+    import json
+    import pickle
+    import subprocess
+    import sys
+
+    import networkx as nx
+    from sklearn.preprocessing import MinMaxScaler
+
+    from gnngls_amd import datasets
+    from gnngls_amd.models import EdgePropertyPredictionModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(3)
+    data = tmp_path / "tsp10"
+    data.mkdir()
+    scalers = {"features": MinMaxScaler(), "regret": MinMaxScaler()}
+    names = []
+    for k in range(12):
+        pos = rng.random((10, 2))
+        G = nx.Graph()
+        for v, p in enumerate(pos):
+            G.add_node(v, pos=p)
+        for i, j in itertools.combinations(G.nodes, 2):
+            w = np.linalg.norm(pos[j] - pos[i])
+            G.add_edge(i, j, weight=w, in_solution=False, regret=float(w * w))     # a learnable target
+        for v in range(10):
+            G.edges[v, (v + 1) % 10]["in_solution"] = True
+        datasets.set_features(G)
+        for key in scalers:
+            scalers[key].partial_fit(np.vstack([G.edges[e][key] for e in G.edges]))
+        pickle.dump(G, open(data / f"i{k}.pkl", "wb"))
+        names.append(f"i{k}.pkl")
+    (data / "train.txt").write_text("\n".join(names[:8]) + "\n")
+    (data / "val.txt").write_text("\n".join(names[8:]) + "\n")
+    pickle.dump(scalers, open(data / "scalers.pkl", "wb"))
+    tb = tmp_path / "tb"
+    cmd = [sys.executable, os.path.join(root, "scripts", "train.py"), str(data), str(tb), "--batch_size", "4",
+           "--n_epochs", "6", "--checkpoint_freq", "2", "--use_gpu", "--num_workers", "0"]
+    subprocess.check_call(cmd, cwd=root)
+    runs = list(tb.iterdir())
+    assert len(runs) == 1
+    files = {p.name for p in runs[0].iterdir()}
+    assert {"checkpoint_best_val.pt", "checkpoint_final.pt", "checkpoint_2.pt", "checkpoint_4.pt", "params.json",
+            "scalars.jsonl"} <= files
+    params = json.load(open(runs[0] / "params.json"))
+    assert params["embed_dim"] == 128 and params["n_heads"] == 8 and params["target"] == "regret"
+    ck = torch.load(runs[0] / "checkpoint_final.pt", map_location="cpu")
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "val_loss"} and ck["epoch"] == 5
+    model = EdgePropertyPredictionModel(1, params["embed_dim"], 1, params["n_layers"], n_heads=params["n_heads"])
+    model.load_state_dict(ck["model_state_dict"])                                   # test.py:50-53
+    scal = [json.loads(line) for line in open(runs[0] / "scalars.jsonl")]
+    train_loss = [r["value"] for r in scal if r["tag"] == "Loss/train"]
+    assert len(train_loss) == 6 and train_loss[-1] < 0.5 * train_loss[0]
+    assert int(ck["model_state_dict"]["message_passing_layers.0.feed_forward.0.num_batches_tracked"]) == 6 * 2
