@@ -317,6 +317,7 @@ struct TrainWs {
     float *G;        // [L][M][128]      GATConv output
     float *H1;       // [L][M][128]      h + GATConv(h)
     float *H3;       // [L][M][128]      x + MLP(x), x = BN1(h1)
+    float *HID;      // [L][M][512]      ReLU(W1 x + b1); overwritten by its gradient in the backward
     float *ATT;      // [L][M][16]       softmax statistics (row max, 1/Z) per head
     float *BN;       // [L][8][128]      mean1 invstd1 scale1 shift1 mean2 invstd2 scale2 shift2
     float *PART;     // [2][M][128]      attention partials (forward) / P partials (backward)
@@ -325,8 +326,8 @@ struct TrainWs {
     float *X2;       // [M][128]         BN1 output recomputed in the backward
     float *DFT;      // [M][128]
     float *DLR;      // [2][M][8]        d el, d er
-    float *BIG;      // [M][512]         hidden activations / their gradient
-    float *COEF;     // [5][128]         BatchNorm backward coefficients (3), ones, zeros
+    float *WT;       // [2][512*128]     W2^T, W1^T of the layer being differentiated
+    float *COEF;     // [3][128] + ones[128] + zeros[512]   BatchNorm backward coefficients, constants
     double *CSP;     // column-sum partials
     float *TNP;      // weight-gradient partial tiles
     size_t bytes;
@@ -342,6 +343,7 @@ TrainWs train_layout(uintptr_t base, long M, int L) {
     w.G = (float *)take(row * L);
     w.H1 = (float *)take(row * L);
     w.H3 = (float *)take(row * L);
+    w.HID = (float *)take(4 * row * L);
     w.ATT = (float *)take((size_t)M * 16 * sizeof(float) * L);
     w.BN = (float *)take((size_t)L * 8 * 128 * sizeof(float));
     w.PART = (float *)take(2 * row);
@@ -351,8 +353,8 @@ TrainWs train_layout(uintptr_t base, long M, int L) {
     w.X2 = (float *)take(row);
     w.DFT = (float *)take(row);
     w.DLR = (float *)take((size_t)2 * M * 8 * sizeof(float));
-    w.BIG = (float *)take(4 * row);
-    w.COEF = (float *)take(5 * 128 * sizeof(float));
+    w.WT = (float *)take((size_t)2 * 512 * 128 * sizeof(float));
+    w.COEF = (float *)take((4 * 128 + 512) * sizeof(float));
     w.CSP = (double *)take((size_t)gnngls::kColsumMaxBlocks * 2 * 512 * sizeof(double));
     w.TNP = (float *)take((size_t)gnngls::gemm_tn_chunks(M) * 128 * 512 * sizeof(float));
     w.bytes = (size_t)(p - base);
@@ -412,7 +414,7 @@ int gnngls_regret_train_forward(const float *feat, const float *params, int B, i
     uint32_t one_bits;
     memcpy(&one_bits, &one, 4);
     GNNGLS_TRY(hipMemsetD32Async((hipDeviceptr_t)ones, (int)one_bits, 128, st));
-    GNNGLS_TRY(hipMemsetAsync(zeros, 0, 128 * sizeof(float), st));
+    GNNGLS_TRY(hipMemsetAsync(zeros, 0, 512 * sizeof(float), st));
     const size_t row = (size_t)M * 128;
     { ProfScope ps(GNNGLS_PROF_EMBED, st);
       GNNGLS_TRY(gnngls::launch_embed(feat, emb_w, emb_b, w.H, M, in_dim, st)); }                       // models.py:66
@@ -435,7 +437,8 @@ int gnngls_regret_train_forward(const float *feat, const float *params, int B, i
           GNNGLS_TRY(gnngls::launch_bn_stats_finalize(w.CSP, nb, M, bn1_g, bn1_b, bn_eps, bn + 2 * 128, bn + 3 * 128, bn,
                                                       bn + 128, stats, stats + 128, st)); }
         { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);                                                      // models.py:28-33
-          GNNGLS_TRY(gnngls::launch_ffn_fused_pre(h1, bn + 2 * 128, bn + 3 * 128, w1, b1, w2, b2, ones, zeros, h3, M, st)); }
+          GNNGLS_TRY(gnngls::launch_ffn_fused_train(h1, bn + 2 * 128, bn + 3 * 128, w1, b1, w2, b2, ones, zeros, h3,
+                                                    w.HID + 4 * row * l, M, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);                                                   // models.py:35 (train mode)
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_SQ, h3, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
           GNNGLS_TRY(gnngls::launch_bn_stats_finalize(w.CSP, nb, M, bn2_g, bn2_b, bn_eps, bn + 6 * 128, bn + 7 * 128,
@@ -485,24 +488,23 @@ int gnngls_regret_train_backward(const float *feat, const float *params, const f
           GNNGLS_TRY(gnngls::launch_bn_bwd_finalize(w.CSP, nb, M, bn2_g, bn + 4 * 128, bn + 5 * 128, d_bn2_g, d_bn2_b, w.COEF, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
           GNNGLS_TRY(gnngls::launch_bn_bwd_apply(w.DA, h3, bn + 4 * 128, w.COEF, w.DB, M, st));
-          GNNGLS_TRY(gnngls::launch_affine_cols(h1, bn + 2 * 128, bn + 3 * 128, w.X2, M, st)); }        // x = BN1(h1), recomputed
+          GNNGLS_TRY(gnngls::launch_affine_cols(h1, bn + 2 * 128, bn + 3 * 128, w.X2, M, st));         // x = BN1(h1), recomputed
+          GNNGLS_TRY(gnngls::launch_transpose(w2, 128, 512, w.WT, st));                                // W2^T [512,128]
+          GNNGLS_TRY(gnngls::launch_transpose(w1, 512, 128, w.WT + 512 * 128, st)); }                  // W1^T [128,512]
         // feed-forward block backward (models.py:28-33): h3 = x + W2 relu(W1 x + b1) + b2
-        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);
-          GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_BIAS_RELU, w.X2, w1, w.BIG, M, 512, 128, b1, nullptr, nullptr, nullptr, st)); }
+        float *hid = w.HID + 4 * row * l;                    // saved ReLU(W1 x + b1)
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
-          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DB, w.BIG, M, 128, 512, w.TNP, d_w2, st)); }
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DB, hid, M, 128, 512, w.TNP, d_w2, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DB, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
           GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, d_b2, nullptr, st)); }
-        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d pre = (d h3 * W2) . [relu > 0], in place over the activations
-          GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_MASK, w.DB, w2, w.BIG, M, 512, 128, w.BIG, st)); }
+        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d x = ((d h3 * W2) . [relu > 0]) * W1 + d h3; hid <- d pre
+          GNNGLS_TRY(gnngls::launch_ffn_fused_bwd(w.DB, w.WT, w.WT + 512 * 128, w.COEF + 3 * 128, w.COEF + 4 * 128, w.DA, hid, M, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
-          GNNGLS_TRY(gnngls::launch_gemm_tn(w.BIG, w.X2, M, 512, 128, w.TNP, d_w1, st)); }
+          GNNGLS_TRY(gnngls::launch_gemm_tn(hid, w.X2, M, 512, 128, w.TNP, d_w1, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
-          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.BIG, nullptr, nullptr, M, 512, 0, w.CSP, &nb, st));
+          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, hid, nullptr, nullptr, M, 512, 0, w.CSP, &nb, st));
           GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 512, 1, d_b1, nullptr, st)); }
-        { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d x = d pre * W1 + d h3 (skip, models.py:15)
-          GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_ADD, w.BIG, w1, w.DA, M, 128, 512, w.DB, st)); }
         // BatchNorm 1 backward (models.py:27): DA = d x -> DB = d h1 (= d h through the skip, = d GATConv output)
         { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DA, h1, nullptr, M, 128, 0, w.CSP, &nb, st));

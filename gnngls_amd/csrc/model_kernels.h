@@ -16,9 +16,12 @@ hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M
 // C[M,N] = A[M,K] * W[K,N] (W row-major [K,N]); epi STORE / MASK (C = acc * (aux > 0)) / ADD (C = acc + aux)
 hipError_t launch_gemm_wkn(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *aux,
                            hipStream_t st);
-hipError_t launch_ffn_fused_pre(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
-                                const float *W2, const float *b2, const float *bn2_s, const float *bn2_b, float *hout,
-                                long M, hipStream_t st);
+hipError_t launch_ffn_fused_train(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, const float *ones, const float *zeros, float *h3,
+                                  float *hidden, long M, hipStream_t st);
+hipError_t launch_ffn_fused_bwd(const float *dh3, const float *W2T, const float *W1T, const float *ones, const float *zeros,
+                                float *dx, float *hidden, long M, hipStream_t st);
+hipError_t launch_transpose(const float *src, int R, int C, float *dst, hipStream_t st);
 hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
                            float *part_ms, hipStream_t st);
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,

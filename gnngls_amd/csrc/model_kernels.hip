@@ -423,16 +423,25 @@ __device__ __forceinline__ void ffn_gemm2_stage(f32x4 (&accY)[8], const f32x4 (&
     }
 }
 
-// PRE (training forward): the x tile is BN1 applied to an already merged h1 = h + GATConv(h) passed in `hin`
-// (part / part_ms unused); the batch statistics of h1 must be known before BN1 can be applied.
-template <bool PRE>
+// Modes.  FFN_INFER: as above.  FFN_TRAIN_FWD: the x tile is BN1 applied to an already merged h1 = h + GATConv(h) passed
+// in `hin` (part / part_ms unused; the batch statistics of h1 must be known before BN1 can be applied) and the hidden
+// activations ReLU(W1 x + b1) are also written to `hid_out` [M,512] for the backward.  FFN_BWD: the SAME two chained
+// GEMMs compute the data gradient of the block, d x = ((d h3 * W2) . [hidden > 0]) * W1 + d h3, when called with
+// hin = d h3, W1 := W2^T [512,128], W2 := W1^T [128,512], zero biases and identity affines: the "activation" becomes the
+// ReLU mask read from `hid_in` (the saved activations) and the masked hidden gradient is written to `hid_out` (it may
+// alias hid_in) for the weight-gradient GEMMs.
+enum { FFN_INFER = 0, FFN_TRAIN_FWD = 1, FFN_BWD = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
                                                            const float *__restrict__ hin,
                                                            const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
                                                            const float *__restrict__ W1, const float *__restrict__ b1,
                                                            const float *__restrict__ W2, const float *__restrict__ b2,
                                                            const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
-                                                           float *__restrict__ hout, long M) {
+                                                           float *__restrict__ hout, long M, const float *hid_in,
+                                                           float *hid_out) {
+    constexpr bool PRE = MODE != FFN_INFER;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);        // [64][LDX]
     float *Wb0 = Xs + FT_M * LDX;                           // [128][LDW]
@@ -530,10 +539,35 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
         FFN_STAGE(1, (ffn_gemm1_stage<1>(accH, Xs, Wt, wrow, lr, lq)))
         FFN_STAGE(2, (ffn_gemm1_stage<2>(accH, Xs, Wt, wrow, lr, lq)))
         FFN_STAGE(3, (ffn_gemm1_stage<3>(accH, Xs, Wt, wrow, lr, lq)))
+        if (MODE == FFN_BWD) {
+            // ReLU backward: keep d hidden where the saved activation is positive (8 float4 loads in flight per lane)
+            const long hrow = row0 + wrow + lr;
+            const bool ok = hrow < M;
+            f32x4 msk[8];
 #pragma unroll
-        for (int ht = 0; ht < 8; ++ht)
+            for (int ht = 0; ht < 8; ++ht)
+                msk[ht] = ok ? *reinterpret_cast<const f32x4 *>(hid_in + hrow * 512 + c * 128 + ht * 16 + 4 * lq)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accH[ht][r] = accH[ht][r] > 0.f ? accH[ht][r] : 0.f;   // ReLU, models.py:31
+            for (int ht = 0; ht < 8; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accH[ht][r] = msk[ht][r] > 0.f ? accH[ht][r] : 0.f;
+        } else {
+#pragma unroll
+            for (int ht = 0; ht < 8; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accH[ht][r] = accH[ht][r] > 0.f ? accH[ht][r] : 0.f;   // ReLU, models.py:31
+        }
+        if (MODE != FFN_INFER) {
+            // lane (lr, lq) holds hidden units 16*ht + 4*lq .. +3 of data row lr: one 16-byte store each, the four lq lanes
+            // of a row complete a 64-byte segment
+            const long hrow = row0 + wrow + lr;
+            if (hrow < M) {
+#pragma unroll
+                for (int ht = 0; ht < 8; ++ht)
+                    *reinterpret_cast<f32x4 *>(hid_out + hrow * 512 + c * 128 + ht * 16 + 4 * lq) = accH[ht];
+            }
+        }
         FFN_STAGE(4, (ffn_gemm2_stage<0>(accY, accH, Wt, lr, lq)))
         FFN_STAGE(5, (ffn_gemm2_stage<1>(accY, accH, Wt, lr, lq)))
         FFN_STAGE(6, (ffn_gemm2_stage<2>(accY, accH, Wt, lr, lq)))
@@ -657,31 +691,58 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
     return hipGetLastError();
 }
 
-hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
-                            const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
-                            const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
+template <int MODE>
+static hipError_t launch_ffn_mode(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
+                                  const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
+                                  const float *bn2_s, const float *bn2_b, float *hout, long M, const float *hid_in,
+                                  float *hid_out, hipStream_t st) {
     const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW + 896) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, part, part_ms, hin,
-                       bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M);
+    hipLaunchKernelGGL(ffn_fused_kernel<MODE>, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, part, part_ms, hin,
+                       bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, hid_in, hid_out);
     return hipGetLastError();
 }
 
-// training forward: h3 = x + W2*ReLU(W1*x + b1) + b2 with x = h1*bn1_s + bn1_b; `bn2_s`/`bn2_b` are passed as
-// ones/zeros by the caller (BatchNorm 2 needs the batch statistics of h3 first)
-hipError_t launch_ffn_fused_pre(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
-                                const float *W2, const float *b2, const float *bn2_s, const float *bn2_b, float *hout,
-                                long M, hipStream_t st) {
-    const size_t lds = (size_t)(FT_M * LDX + 2 * 128 * LDW + 896) * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
+                            const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
+    return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,
+                                      nullptr, st);
+}
+
+// training forward: h3 = x + W2*ReLU(W1*x + b1) + b2 with x = h1*bn1_s + bn1_b, hidden activations kept in `hidden`
+// [M,512]; `bn2_s`/`bn2_b` are passed as ones/zeros by the caller (BatchNorm 2 needs the batch statistics of h3 first)
+hipError_t launch_ffn_fused_train(const float *h1, const float *bn1_s, const float *bn1_b, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, const float *ones, const float *zeros, float *h3,
+                                  float *hidden, long M, hipStream_t st) {
+    return launch_ffn_mode<FFN_TRAIN_FWD>(nullptr, nullptr, h1, bn1_s, bn1_b, W1, b1, W2, b2, ones, zeros, h3, M, nullptr,
+                                          hidden, st);
+}
+
+// data gradient of the block: dx = ((dh3 * W2) . [hidden > 0]) * W1 + dh3; `hidden` [M,512] holds the saved activations
+// on entry and the masked hidden gradient on exit; W2T [512,128] / W1T [128,512] are the transposed weights;
+// zeros must hold 512 floats, ones 128
+hipError_t launch_ffn_fused_bwd(const float *dh3, const float *W2T, const float *W1T, const float *ones, const float *zeros,
+                                float *dx, float *hidden, long M, hipStream_t st) {
+    return launch_ffn_mode<FFN_BWD>(nullptr, nullptr, dh3, ones, zeros, W2T, zeros, W1T, zeros, ones, zeros, dx, M, hidden,
+                                    hidden, st);
+}
+
+// dst[C,R] = src[R,C]^T (weight matrices, 64K elements)
+__global__ void transpose_kernel(const float *__restrict__ src, int R, int C, float *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = src[(long)(r0 + i) * C + c0 + threadIdx.x];
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) dst[(long)(c0 + i) * R + r0 + threadIdx.x] = tile[threadIdx.x][i];
+}
+
+hipError_t launch_transpose(const float *src, int R, int C, float *dst, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3((unsigned)((M + FT_M - 1) / FT_M)), dim3(256), lds, st, nullptr, nullptr, h1,
-                       bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M);
+    hipLaunchKernelGGL(transpose_kernel, dim3(C / 32, R / 32), dim3(32, 8), 0, st, src, R, C, dst);
     return hipGetLastError();
 }
 
