@@ -376,6 +376,9 @@ int train_check(const char *what, const void *feat, const void *params, const vo
                 int in_dim, int n_layers, int64_t workspace_bytes) {
     if (!feat || !params || !io || !workspace || B < 1 || n < 3 || in_dim < 1 || n_layers < 0)
         return fail(GNNGLS_ERR_ARG, "%s: bad argument", what);
+    if (n > gnngls::gat_bwd_max_nodes())
+        return fail(GNNGLS_ERR_UNSUPPORTED, "%s: n=%d exceeds the attention-backward tile limit (n <= %d)", what, n,
+                    gnngls::gat_bwd_max_nodes());
     if (gnngls::gat_rows_lds_bytes(n) > kLdsPerCU || gnngls::gat_bwd_lds_bytes(n) > kLdsPerCU)
         return fail(GNNGLS_ERR_UNSUPPORTED, "%s: n=%d needs %zu B of LDS per row tile (> 160 KiB)", what, n,
                     gnngls::gat_bwd_lds_bytes(n));

@@ -27,6 +27,7 @@ hipError_t launch_outer_rows(const float *dy, const float *w, float *dh, long M,
 hipError_t launch_gat_combine_train(const float *part, const float *part_ms, const float *h, long M, float *g, float *h1,
                                     float *att, hipStream_t st);
 size_t gat_bwd_lds_bytes(int n);
+int gat_bwd_max_nodes();
 hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *gout, const float *att, const float *attn_l,
                                const float *attn_r, int B, int n, float *P, float *dlr, hipStream_t st);
 hipError_t launch_gat_bwd_combine(const float *P, const float *dlr, const float *attn_l, const float *attn_r, long M,

@@ -265,11 +265,14 @@ __global__ void gat_combine_train_kernel(const float *__restrict__ part, const f
 // written to side (u < k ? 0 : 1) of the partial buffers; the other endpoint's row supplies the second half.
 // gat_bwd_combine_kernel then forms  dft = P + del*attn_l + der*attn_r  (el = <ft,attn_l>, er = <ft,attn_r>).
 // ---------------------------------------------------------------------------------------------
-constexpr int LDG = 132;   // LDS row stride (floats): a ds_read_b128 of 16 consecutive rows at one column offset touches
-                           // 16 disjoint groups of 4 banks; 4 rows 4 apart (MFMA B fragment) land on disjoint 16-bank groups
-
-constexpr int kGatBwdThreads = 512;   // 8 waves = one per attention head
-constexpr int kGatBwdMaxTiles = 9;    // 16-node tiles per row: n - 1 <= 144 (the LDS tile limits n to 135 anyway)
+constexpr int kGatBwdHeads = 2;                    // heads per workgroup (one wave each): the LDS tile of a workgroup covers
+                                                   // 16*kGatBwdHeads columns of ft / dOut, so several workgroups share a CU
+                                                   // and the staging of one overlaps the MFMA phase of the others
+constexpr int kGatBwdThreads = 64 * kGatBwdHeads;
+constexpr int kGatBwdMaxTiles = 9;                 // 16-node tiles per row: n - 1 <= 144
+constexpr int LDG = 16 * kGatBwdHeads + 4;         // LDS row stride (floats): a ds_read_b128 of 16 consecutive rows at one
+                                                   // column offset touches 16 disjoint groups of 4 banks; 4 rows 4 apart
+                                                   // (MFMA B fragment) land on disjoint 16-bank groups  (36, 68, 132)
 
 __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over the 16-lane DPP row; lane 15 holds the total
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
@@ -279,26 +282,31 @@ __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over
     return v;
 }
 
-// Wave h owns head h.  Outer loop: destination tiles dt (dOut fragments, softmax statistics and the B fragments of the
-// second product are fetched once per tile); inner loop: source tiles st, whose P / del accumulators stay in registers
-// for the whole kernel (kGatBwdMaxTiles x 5 VGPRs), while der of the current destination tile accumulates across st and
-// is reduced over the 16 source lanes once per tile.
+// Workgroup = (instance b, TSP row u, head group); wave w owns head h = group * kGatBwdHeads + w.  Outer loop:
+// destination tiles dt (dOut fragments, softmax statistics and the B fragments of the second product are fetched once
+// per tile); inner loop: source tiles st, whose P / del accumulators stay in registers for the whole kernel
+// (kGatBwdMaxTiles x 5 VGPRs), while der of the current destination tile accumulates across st and is reduced over the
+// 16 source lanes once per tile.
 __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const float *__restrict__ ft, const float *__restrict__ dout,
                                                                       const float *__restrict__ gout, const float *__restrict__ att,
                                                                       const float *__restrict__ attn_l, const float *__restrict__ attn_r,
                                                                       int n, float *__restrict__ P, float *__restrict__ dlr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HG = kGatBwdHeads, CW = 16 * HG;                // heads / columns per workgroup
+    constexpr int groups = kH / HG;
     const int N = n * (n - 1) / 2;
     const int ns = n - 1, nt = (ns + 15) >> 4;
-    const int b = blockIdx.x / n, u = blockIdx.x % n;
-    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
-    float *ftS = reinterpret_cast<float *>(smem);                 // [ns][LDG]
+    const int grp = blockIdx.x % groups, bu = blockIdx.x / groups;
+    const int b = bu / n, u = bu % n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = grp * HG + w, c0 = grp * CW;
+    f32x4 *stS = reinterpret_cast<f32x4 *>(smem);                 // [ns][HG] (er, -max*log2e, 1/Z, c)   (16-byte rows first)
+    float *ftS = reinterpret_cast<float *>(stS + (size_t)ns * HG);  // [ns][LDG]  columns c0 .. c0+CW of ft
     float *dgS = ftS + (size_t)ns * LDG;                          // [ns][LDG]
-    float *elS = dgS + (size_t)ns * LDG;                          // [ns][8]
-    f32x4 *stS = reinterpret_cast<f32x4 *>(elS + (size_t)ns * kH);  // [ns][8] (er, -max*log2e, 1/Z, c)
-    int *nodeS = reinterpret_cast<int *>(stS + (size_t)ns * kH);  // [ns] line-graph node of slot s
+    float *elS = dgS + (size_t)ns * LDG;                          // [ns][HG]
+    int *nodeS = reinterpret_cast<int *>(elS + (size_t)ns * HG);  // [ns] line-graph node of slot s
     const float kLog2e = 1.4426950408889634f;
-    const size_t Mtot = (size_t)gridDim.x / n * N;                // B*N rows per side
+    const size_t Mtot = (size_t)gridDim.x / (n * groups) * N;     // B*N rows per side
 
     const size_t base = (size_t)b * N;
     for (int s = tid; s < ns; s += kGatBwdThreads) {
@@ -306,17 +314,17 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
         nodeS[s] = k < u ? tri_index(k, u, n) : tri_index(u, k, n);
     }
     __syncthreads();
-    for (int q = tid; q < ns * (kD / 4); q += kGatBwdThreads) {
-        const int s = q >> 5, c = (q & 31) * 4;
-        const size_t row = (base + nodeS[s]) * kD + c;
+    for (int q = tid; q < ns * (CW / 4); q += kGatBwdThreads) {
+        const int s = q / (CW / 4), c = (q % (CW / 4)) * 4;
+        const size_t row = (base + nodeS[s]) * kD + c0 + c;
         *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(ft + row);
         *reinterpret_cast<f32x4 *>(dgS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(dout + row);
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += kGatBwdThreads) {
-        const int s = q >> 3, hh = q & 7;
-        const float *f = ftS + (size_t)s * LDG + hh * kF;
-        const float *d = dgS + (size_t)s * LDG + hh * kF;
+    for (int q = tid; q < ns * HG; q += kGatBwdThreads) {
+        const int s = q / HG, hl = q % HG, hh = grp * HG + hl;
+        const float *f = ftS + (size_t)s * LDG + hl * kF;
+        const float *d = dgS + (size_t)s * LDG + hl * kF;
         const float *go = gout + (base + nodeS[s]) * kD + hh * kF;
         float l = 0.f, r = 0.f, c = 0.f;
 #pragma unroll
@@ -342,23 +350,23 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
     for (int dt = 0; dt < nt; ++dt) {
         const int ia = dt * 16 + jl, iac = ia < ns ? ia : ns - 1;
         // A operand of T = dOut * ft^T: lane (jl, q4) supplies dOut[i = 16dt + jl][16h + 4*q4 + ks] (one ds_read_b128)
-        const f32x4 adg = *reinterpret_cast<const f32x4 *>(dgS + (size_t)iac * LDG + h * kF + 4 * q4);
+        const f32x4 adg = *reinterpret_cast<const f32x4 *>(dgS + (size_t)iac * LDG + w * kF + 4 * q4);
         f32x4 sv[4];
         float bdg[4], der[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = dt * 16 + 4 * q4 + r, ic = i < ns ? i : ns - 1;
-            sv[r] = stS[ic * kH + h];
-            bdg[r] = dgS[(size_t)ic * LDG + h * kF + jl];
+            sv[r] = stS[ic * HG + w];
+            bdg[r] = dgS[(size_t)ic * LDG + w * kF + jl];
             der[r] = 0.f;
         }
 #pragma unroll
         for (int st = 0; st < kGatBwdMaxTiles; ++st) {
             if (st < nt) {
                 const int j = st * 16 + jl, jc = j < ns ? j : ns - 1;
-                const float el_j = elS[jc * kH + h];
+                const float el_j = elS[jc * HG + w];
                 // B operand: lane (jl, q4) supplies ft[j][16h + 4*q4 + ks]
-                const f32x4 bft = *reinterpret_cast<const f32x4 *>(ftS + (size_t)jc * LDG + h * kF + 4 * q4);
+                const f32x4 bft = *reinterpret_cast<const f32x4 *>(ftS + (size_t)jc * LDG + w * kF + 4 * q4);
                 f32x4 T = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) T = __builtin_amdgcn_mfma_f32_16x16x4f32(adg[ks], bft[ks], T, 0, 0, 0);
@@ -601,10 +609,12 @@ hipError_t launch_gat_combine_train(const float *part, const float *part_ms, con
     return hipGetLastError();
 }
 
+int gat_bwd_max_nodes() { return 16 * kGatBwdMaxTiles + 1; }   // register-resident accumulators: one per 16-node source tile
+
 size_t gat_bwd_lds_bytes(int n) {
     const size_t ns = (size_t)n - 1, nt = (ns + 15) / 16, nsp = nt * 16;
     (void)nt; (void)nsp;
-    return 2 * ns * LDG * 4 + ns * kH * 4 + ns * kH * 16 + ns * 4 + 16;
+    return 2 * ns * LDG * 4 + ns * kGatBwdHeads * 4 + ns * kGatBwdHeads * 16 + ns * 4 + 16;
 }
 
 hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *gout, const float *att, const float *attn_l,
@@ -614,7 +624,7 @@ hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_bwd_rows_kernel, dim3((unsigned)(B * n)), dim3(kGatBwdThreads), lds, st, ft, dout, gout, att, attn_l, attn_r, n,
+    hipLaunchKernelGGL(gat_bwd_rows_kernel, dim3((unsigned)(B * n * (kH / kGatBwdHeads))), dim3(kGatBwdThreads), lds, st, ft, dout, gout, att, attn_l, attn_r, n,
                        P, dlr);
     return hipGetLastError();
 }

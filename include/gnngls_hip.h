@@ -154,7 +154,7 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
  *   forward : feat [B,N,in_dim] -> y_out [B,N]; bn_batch_stats [n_layers][2 (BN1, BN2)][2 (mean, unbiased var)][128]
  *             is what the caller folds into running_mean / running_var (momentum update, torch semantics).
  *   backward: must follow a forward on the SAME workspace (activations are kept there); writes every gradient.
- * n is limited by the LDS tile of the attention backward (n <= 135).  GATConv bias (DGL >= 0.7) is not supported. */
+ * n is limited by the register-resident source tiles of the attention backward (n <= 145).  GATConv bias (DGL >= 0.7) is not supported. */
 int64_t gnngls_regret_train_workspace_bytes(int B, int n, int n_layers);
 int gnngls_regret_train_forward(const float *feat, const float *params, int B, int n, int in_dim, int n_layers, float bn_eps,
                                 float *y_out, float *bn_batch_stats, void *workspace, int64_t workspace_bytes, void *stream);

@@ -188,7 +188,7 @@ def test_training_rejects_unsupported_sizes():
     from gnngls_amd.models import LineGraph
     model, _ = make_models(4321, 77)
     model.train()
-    n = 140                                     # attention-backward tile needs more than 160 KiB of LDS
+    n = 150                                     # beyond the attention-backward tile limit (n <= 145)
     x = torch.zeros((n * (n - 1) // 2, 1), device="cuda")
     with pytest.raises(_lib.GnnglsHipError):
         model(LineGraph(n).to("cuda"), x)
