@@ -356,7 +356,7 @@ TrainWs train_layout(uintptr_t base, long M, int L) {
     w.WT = (float *)take((size_t)2 * 512 * 128 * sizeof(float));
     w.COEF = (float *)take((4 * 128 + 512) * sizeof(float));
     w.CSP = (double *)take((size_t)gnngls::kColsumMaxBlocks * 2 * 512 * sizeof(double));
-    w.TNP = (float *)take((size_t)gnngls::gemm_tn_chunks(M) * 128 * 512 * sizeof(float));
+    w.TNP = (float *)take((size_t)gnngls::gemm_tn_chunks(M) * (128 * 512 + 512) * sizeof(float));
     w.bytes = (size_t)(p - base);
     return w;
 }
@@ -497,17 +497,11 @@ int gnngls_regret_train_backward(const float *feat, const float *params, const f
         // feed-forward block backward (models.py:28-33): h3 = x + W2 relu(W1 x + b1) + b2
         float *hid = w.HID + 4 * row * l;                    // saved ReLU(W1 x + b1)
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
-          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DB, hid, M, 128, 512, w.TNP, d_w2, st)); }
-        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
-          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DB, nullptr, nullptr, M, 128, 0, w.CSP, &nb, st));
-          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, d_b2, nullptr, st)); }
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DB, hid, M, 128, 512, w.TNP, d_w2, d_b2, st)); }   // d W2 and d b2 = colsum(d h3)
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d x = ((d h3 * W2) . [relu > 0]) * W1 + d h3; hid <- d pre
           GNNGLS_TRY(gnngls::launch_ffn_fused_bwd(w.DB, w.WT, w.WT + 512 * 128, w.COEF + 3 * 128, w.COEF + 4 * 128, w.DA, hid, M, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
-          GNNGLS_TRY(gnngls::launch_gemm_tn(hid, w.X2, M, 512, 128, w.TNP, d_w1, st)); }
-        { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
-          GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, hid, nullptr, nullptr, M, 512, 0, w.CSP, &nb, st));
-          GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 512, 1, d_b1, nullptr, st)); }
+          GNNGLS_TRY(gnngls::launch_gemm_tn(hid, w.X2, M, 512, 128, w.TNP, d_w1, d_b1, st)); }   // d W1 and d b1 = colsum(d pre)
         // BatchNorm 1 backward (models.py:27): DA = d x -> DB = d h1 (= d h through the skip, = d GATConv output)
         { ProfScope ps(GNNGLS_PROF_TRAIN_COLSUM, st);
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DA, h1, nullptr, M, 128, 0, w.CSP, &nb, st));
@@ -523,7 +517,7 @@ int gnngls_regret_train_backward(const float *feat, const float *params, const f
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_HEADSCALE, ft, w.DLR, w.DLR + (size_t)M * 8, M, 128, 0, w.CSP, &nb, st));
           GNNGLS_TRY(gnngls::launch_colsum_store(w.CSP, nb, 128, 1, d_attn_l, d_attn_r, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);
-          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DFT, h, M, 128, 128, w.TNP, d_fc_w, st)); }
+          GNNGLS_TRY(gnngls::launch_gemm_tn(w.DFT, h, M, 128, 128, w.TNP, d_fc_w, nullptr, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_BWD, st);      // d h = d ft * Wfc + d h1 (skip, models.py:15)
           GNNGLS_TRY(gnngls::launch_gemm_wkn(gnngls::GEMM_EPI_ADD, w.DFT, fc_w, w.DA, M, 128, 128, w.DB, st)); }
     }

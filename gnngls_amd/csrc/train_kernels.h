@@ -33,7 +33,9 @@ hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *
 hipError_t launch_gat_bwd_combine(const float *P, const float *dlr, const float *attn_l, const float *attn_r, long M,
                                   float *dft, float *dl, float *dr, hipStream_t st);
 int gemm_tn_chunks(long M);
-// out[N1,N2] = X[M,N1]^T * Y[M,N2]; `partial` holds gemm_tn_chunks(M) * N1 * N2 floats
-hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2, float *partial, float *out, hipStream_t st);
+// out[N1,N2] = X[M,N1]^T * Y[M,N2] and, if xsum_out, xsum_out[N1] = column sums of X;
+// `partial` holds gemm_tn_chunks(M) * (N1 * N2 + N1) floats
+hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2, float *partial, float *out,
+                          float *xsum_out, hipStream_t st);
 
 }  // namespace gnngls

@@ -443,8 +443,11 @@ __global__ void gat_bwd_combine_kernel(const float *__restrict__ P, const float 
 // ---------------------------------------------------------------------------------------------
 constexpr int TBK = 32, TLD = 129;
 
+// xsum (optional): the column sums of X over the chunk's rows, [chunk][N1] -- the bias gradient that goes with the weight
+// gradient (X = d output of the Linear), taken from the LDS image of X the tile loop has staged anyway.
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ X, const float *__restrict__ Y, long M, int N1,
-                                                      int N2, long rows_per_chunk, float *__restrict__ partial) {
+                                                      int N2, long rows_per_chunk, float *__restrict__ partial,
+                                                      float *__restrict__ xsum) {
     __shared__ float Xs[TBK * TLD];
     __shared__ float Ys[TBK * TLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -480,12 +483,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
                 Ys[(8 * uu + tk) * TLD + tc + c] = ry[uu][c];
             }
     };
+    const bool want_xsum = xsum != nullptr && blockIdx.z == 0;
+    float xs = 0.f;
     if (m_lo < m_hi) gload(m_lo);
     for (long m0 = m_lo; m0 < m_hi; m0 += TBK) {
         __syncthreads();
         lstore();
         __syncthreads();
         if (m0 + TBK < m_hi) gload(m0 + TBK);
+        if (want_xsum) {                                   // thread -> column tid & 127, k half tid >> 7 (rows past m_hi are zero)
+            const float *xc = Xs + (tid >> 7) * 16 * TLD + (tid & 127);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xs += xc[k * TLD];
+        }
         const int lr = lane & 31, lk = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < TBK; kk += 2) {
@@ -497,6 +507,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+    }
+    if (want_xsum) {
+        __syncthreads();
+        if (tid >= 128) Xs[tid & 127] = xs;
+        __syncthreads();
+        if (tid < 128) xsum[(size_t)blockIdx.x * N1 + c1 + tid] = xs + Xs[tid];
     }
     float *out = partial + (size_t)blockIdx.x * N1 * N2;
     const int lc = lane & 31, lh = lane >> 5;
@@ -641,16 +657,20 @@ int gemm_tn_chunks(long M) {
     return grid_cap(c, kGemmTnMaxChunks);
 }
 
-hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2, float *partial, float *out, hipStream_t st) {
+hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2, float *partial, float *out,
+                          float *xsum_out, hipStream_t st) {
     const int chunks = gemm_tn_chunks(M);
     long rows = (M + chunks - 1) / chunks;
     rows = (rows + TBK - 1) / TBK * TBK;
+    const long E = (long)N1 * N2;
+    float *xpart = xsum_out ? partial + (size_t)chunks * E : nullptr;      // [chunks][N1] behind the tile partials
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(chunks, N1 / 128, N2 / 128), dim3(256), 0, st, X, Y, M, N1, N2, rows, partial);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(chunks, N1 / 128, N2 / 128), dim3(256), 0, st, X, Y, M, N1, N2, rows, partial, xpart);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long E = (long)N1 * N2;
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, partial, chunks, E, out);
+    if (xsum_out)
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((N1 + 63) / 64)), dim3(256), 0, st, xpart, chunks, (long)N1, xsum_out);
     return hipGetLastError();
 }
 
