@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
     n, B = args.n, args.batch
     N = n * (n - 1) // 2
@@ -78,7 +79,30 @@ def main():
            "model_tflops": (fwd + bwd) * B / (ms * 1e-3) / 1e12,
            "kernel_ms_per_step": sum(v["ms_per_step"] for v in kern.values()), "kernels": kern,
            "workspace_gib": _lib.load().gnngls_regret_train_workspace_bytes(B, n, 8) / 2 ** 30}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n)
     print(json.dumps(out))
+
+
+def cpu_baseline(n):
+    """The CPU oracle (plain PyTorch fp32 autograd of the reference's graph, oracle/model_oracle.py) on a bounded sample:
+    one forward+backward+Adam step on a batch of ONE instance of the same size, all host cores."""
+    from oracle import model_oracle as mo
+    torch.manual_seed(0)
+    model = mo.EdgeRegretModelOracle(1, 128, 1, 3, n_heads=8).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    N = n * (n - 1) // 2
+    G = mo.batch_line_graphs(n, 1)
+    x, y = torch.rand(N, 1), torch.rand(N, 1)
+    t0 = time.time()
+    opt.zero_grad()
+    loss = torch.nn.functional.mse_loss(model(G, x), y)
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "instances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one training step on a batch of 1 TSP{n} instance (fp32 torch autograd of the oracle graph)",
+            "wall_s": dt}
 
 
 if __name__ == "__main__":
