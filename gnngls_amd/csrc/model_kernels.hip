@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 constexpr int LDF = kD + 16;   // LDS row stride of the staged ft tile (floats): the 4 source rows an MFMA
                                // B-fragment read touches land on 4 disjoint groups of 16 banks
 
-__global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__ ft, const float *__restrict__ attn_l,
+__global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__ ft, const float *__restrict__ attn_l,
                                                        const float *__restrict__ attn_r, int n,
                                                        float *__restrict__ part, float *__restrict__ part_ms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
     const int ns = n - 1;
     const int b = blockIdx.x / n, i = blockIdx.x % n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 4..8 waves, chosen by the launcher to balance the units
     float *ftS = reinterpret_cast<float *>(smem);            // [ns][LDF]
     float *elS = ftS + (size_t)ns * LDF;                     // [ns][8]
     float *erS = elS + (size_t)ns * kH;                      // [ns][8]
@@ -247,18 +248,18 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
     int *nodeS = reinterpret_cast<int *>(top + kH * 4);      // [ns] global node id of slot
 
     const float *ftb = ft + (size_t)b * N * kD;
-    for (int s = tid; s < ns; s += 256) {
+    for (int s = tid; s < ns; s += nthreads) {
         int k = s < i ? s : s + 1;
         nodeS[s] = k < i ? pair_index(k, i, n) : pair_index(i, k, n);
     }
     __syncthreads();
-    for (int q = tid; q < ns * (kD / 4); q += 256) {         // stage ft rows: 32 x 16 B per node, coalesced
+    for (int q = tid; q < ns * (kD / 4); q += nthreads) {         // stage ft rows: 32 x 16 B per node, coalesced
         int s = q >> 5, c = (q & 31) * 4;
         *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDF + c) =
             *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[s] * kD + c);
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += 256) {               // el / er (GATConv: (feat * attn).sum(-1))
+    for (int q = tid; q < ns * kH; q += nthreads) {               // el / er (GATConv: (feat * attn).sum(-1))
         int s = q >> 3, h = q & 7;
         const float *f = ftS + (size_t)s * LDF + h * kF;
         float l = 0.f, r = 0.f;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
         elS[q] = l; erS[q] = r;
     }
     __syncthreads();
-    {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles
+    if (tid < 256) {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles
         const int h = tid >> 5, l32 = tid & 31;
         float m1 = -INFINITY, m2 = -INFINITY; int a1 = -1;
         for (int s = l32; s < ns; s += 32) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void gat_rows_kernel(const float *__restrict__
     float *mb = part_ms + (size_t)b * N * (2 * kH);
     const size_t side_stride = (size_t)gridDim.x / n * N;     // B*N nodes per side
     constexpr int HU = 4;                                      // heads per unit (independent MFMA chains)
-    for (int unit = wave; unit < n_dt * (kH / HU); unit += 4) {
+    for (int unit = wave; unit < n_dt * (kH / HU); unit += nwaves) {
         const int dt = unit / (kH / HU), h0 = (unit % (kH / HU)) * HU;
         const int js = dt * 16 + jl;
         const int jsc = js < ns ? js : ns - 1;
@@ -687,7 +688,12 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(256), lds, st, ft, attn_l, attn_r, n, part, part_ms);
+    // units = (16-destination tiles) x (2 head quads); the wave count that needs the fewest rounds, fewest waves on ties
+    const int units = ((n - 1 + 15) / 16) * 2;
+    int waves = 4;
+    for (int w = 5; w <= 8; ++w)
+        if ((units + w - 1) / w < (units + waves - 1) / waves) waves = w;
+    hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(64 * waves), lds, st, ft, attn_l, attn_r, n, part, part_ms);
     return hipGetLastError();
 }
 
