@@ -39,12 +39,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (forward, loss, backward, Adam) in one HIP graph and replay it")
     args = ap.parse_args()
     n, B = args.n, args.batch
     N = n * (n - 1) // 2
     torch.manual_seed(0)
     model = models.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8).cuda().train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)                         # train.py:104
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=args.graph)   # train.py:104
     crit = torch.nn.MSELoss()                                                   # train.py:108
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32)).cuda()
@@ -52,20 +54,35 @@ def main():
     G = models.LineGraph(n, batch=B).to("cuda")
 
     def step():
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=not args.graph)
         loss = crit(model(G, x), y)
         loss.backward()
         if not args.no_optimizer:
             opt.step()
         return loss
 
-    for _ in range(args.warmup):
-        step()
+    if args.graph:
+        # torch.cuda.graphs "whole network capture": every launch the C ABI enqueues on torch's current stream is recorded
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=False)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        run = lambda: (graph.replay(), static_loss)[1]  # noqa: E731
+    else:
+        run = step
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
-    _lib.profile_enable(True)
+    _lib.profile_enable(not args.graph)
     t0 = time.time()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     dt = time.time() - t0
     prof = _lib.profile_collect()
@@ -84,12 +101,14 @@ def main():
         if k in kern:
             kern[k]["tflops"] = f / (kern[k]["ms_per_step"] * 1e-3) / 1e12
             kern[k]["frac_of_mfma_peak"] = kern[k]["tflops"] / 157.3
-    top = max((k for k in algo if k in kern), key=lambda k: kern[k]["ms_per_step"])
-    roofline = {"bound": "mfma", "kernel": top, "achieved": kern[top]["tflops"], "peak": 157.3, "unit": "TFLOP/s",
-                "frac": kern[top]["tflops"] / 157.3, "traffic": None}
+    roofline = None
+    if kern:
+        top = max((k for k in algo if k in kern), key=lambda k: kern[k]["ms_per_step"])
+        roofline = {"bound": "mfma", "kernel": top, "achieved": kern[top]["tflops"], "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": kern[top]["tflops"] / 157.3, "traffic": None}
     out = {"metric": "training steps/sec (forward+backward+Adam)", "value": args.steps / dt, "unit": "steps/s",
            "instances_per_s": B * args.steps / dt, "ms_per_step": ms, "n": n, "batch": B, "steps": args.steps,
-           "warmup": args.warmup, "dtype": "f32", "data": "synthetic", "loss": float(loss.item()),
+           "warmup": args.warmup, "hip_graph": bool(args.graph), "dtype": "f32", "data": "synthetic", "loss": float(loss.item()),
            "model_tflops": (fwd + bwd) * B / (ms * 1e-3) / 1e12,
            "kernel_ms_per_step": sum(v["ms_per_step"] for v in kern.values() if "ms_per_step" in v), "roofline": roofline,
            "kernels": kern,

@@ -251,3 +251,48 @@ def test_train_cli_end_to_end(tmp_path):
     train_loss = [r["value"] for r in scal if r["tag"] == "Loss/train"]
     assert len(train_loss) == 6 and train_loss[-1] < 0.5 * train_loss[0]
     assert int(ck["model_state_dict"]["message_passing_layers.0.feed_forward.0.num_batches_tracked"]) == 6 * 2
+
+
+def test_whole_step_hip_graph_replay_matches_eager():
+    """torch.cuda.graphs whole-step capture (forward, loss, backward, Adam): every launch of the C ABI lands on torch's
+    capturing stream, so the replayed steps must reproduce the eager steps bit for bit (the step is deterministic)."""
+    from gnngls_amd.models import LineGraph
+    n, B = 8, 2
+    N = n * (n - 1) // 2
+    rng = np.random.default_rng(21)
+    x = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32)).cuda()
+    t = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32)).cuda()
+    G = LineGraph(n, batch=B).to("cuda")
+
+    def make():
+        model, _ = make_models(4321, 77)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            loss = torch.nn.functional.mse_loss(model(G, x), t)
+            loss.backward()
+            opt.step()
+            return loss
+        return model, step
+
+    _, eager = make()
+    eager_losses = [eager().item() for _ in range(5)]
+
+    model, step = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = step()
+    replay_losses = []
+    for _ in range(2):
+        graph.replay()
+        replay_losses.append(static_loss.item())
+    assert replay_losses == eager_losses[3:5]
+    assert int(model.batch_norms()[0].num_batches_tracked) == 5
