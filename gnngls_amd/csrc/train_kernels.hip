@@ -654,8 +654,8 @@ hipError_t launch_gat_bwd_combine(const float *P, const float *dlr, const float 
     return hipGetLastError();
 }
 
-int gemm_tn_chunks(long M) {
-    long c = (M + 511) / 512;
+int gemm_tn_chunks(long M) {           // >= 128 rows (4 k-tiles) per chunk, at most kGemmTnMaxChunks chunks
+    long c = (M + 127) / 128;
     return grid_cap(c, kGemmTnMaxChunks);
 }
 
