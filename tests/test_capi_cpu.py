@@ -45,6 +45,24 @@ def test_host_queries(lib):
     assert lib.gnngls_regret_forward_workspace_bytes(2, 100) > 2 * 4950 * 128 * 4 * 5
 
 
+def test_training_entry_points_host_side(lib):
+    """Workspace query grows with batch, size and depth; argument checks fire before any HIP call (no GPU here)."""
+    w = lib.gnngls_regret_train_workspace_bytes
+    assert w(0, 100, 8) == 0 and w(1, 100, 8) > 0
+    assert w(2, 100, 8) > w(1, 100, 8) and w(1, 100, 8) > w(1, 50, 8) and w(1, 100, 8) > w(1, 100, 4)
+    rows = 4950
+    assert w(1, 100, 8) >= rows * 4 * (9 * 128 + 8 * (4 * 128 + 512 + 16))        # saved activations alone
+    assert lib.gnngls_regret_train_forward(None, None, 1, 100, 1, 8, 1e-5, None, None, None, 0, None) == -1
+    assert b"regret_train_forward" in lib.gnngls_last_error()
+    assert lib.gnngls_regret_train_backward(None, None, None, 1, 100, 1, 8, None, None, 0, None) == -1
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.gnngls_regret_train_forward(p, p, 1, 150, 1, 8, 1e-5, p, p, p, 1 << 40, None) == -3      # n > 145
+    assert b"tile limit" in lib.gnngls_last_error()
+    assert lib.gnngls_regret_train_forward(p, p, 1, 100, 1, 8, 1e-5, p, p, p, 1024, None) == -1         # workspace too small
+    assert b"workspace too small" in lib.gnngls_last_error()
+
+
 def test_bad_arguments_are_rejected(lib):
     from gnngls_amd import _lib
     assert lib.gnngls_tour_cost(None, None, 1, 5, None, None) == -1
