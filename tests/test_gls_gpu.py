@@ -310,3 +310,21 @@ def test_full_size_batch_properties(ops):
     assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
     assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all()
     assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("n,B,K,min_optimal,max_mean_gap", [(14, 32, 200, 0.95, 0.05), (20, 16, 400, 0.75, 0.5)])
+def test_search_against_exact_optimum(n, B, K, min_optimal, max_mean_gap):
+    """The true optimality gap (test.py:104) on instances small enough for the Held-Karp DP (oracle/held_karp.c): no
+    result may beat the optimum, and guided local search closes almost all of them."""
+    from gnngls_amd import ops
+    from oracle import held_karp
+    rng = np.random.default_rng(1000 + n)
+    pos = rng.random((B, n, 2))
+    D_host = np.linalg.norm(pos[:, :, None] - pos[:, None], axis=3)
+    opt = held_karp.optima(D_host, workers=4)
+    D = torch.from_numpy(D_host).cuda()
+    init = ops.nearest_neighbor(D)
+    r = ops.gls_run(D, D[None].contiguous(), init, ops.tour_cost(init, D), perturbation_moves=20, max_outer_iters=K)
+    gap = r.best_cost.cpu().numpy() / opt - 1.0
+    assert gap.min() >= -1e-12
+    assert (gap <= 1e-12).mean() >= min_optimal and gap.mean() * 100 <= max_mean_gap, (gap.mean() * 100, (gap <= 1e-12).mean())
