@@ -46,6 +46,9 @@ def parse_args():
     parser.add_argument('--perturbation_moves', type=int, default=20)
     parser.add_argument('--use_gpu', action='store_true')
     parser.add_argument('--batch_size', type=int, default=0, help='instances searched concurrently (0 = device capacity)')
+    parser.add_argument('--per_batch_budget', type=int, default=0, metavar='R',
+                        help='search R x batch_size instances within ONE --time_limit (each gets time_limit / R) '
+                             'instead of giving every instance the full budget')
     return parser.parse_args()
 
 
@@ -71,7 +74,7 @@ def load_model(args, params, test_set):
     return model.to(device).eval(), pipeline.Scalers.from_sklearn(test_set.scalers)
 
 
-def solve_block(names, test_set, model, scalers, args, chunk):
+def solve_block(names, test_set, model, scalers, args, chunk, budget='per_instance'):
     """One batch of instances -> (search-progress records, gaps), the body of the loop at test.py:59-109."""
     graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
     optima = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
@@ -80,7 +83,7 @@ def solve_block(names, test_set, model, scalers, args, chunk):
     records = [{'instance': name, 'time': started, 'opt_cost': opt} for name, opt in zip(names, optima)]
     res = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
                                perturbation_moves=args.perturbation_moves, trace_cap=TRACE_CAP, want_trace_time=True,
-                               chunk=chunk)
+                               chunk=chunk, budget=budget)
     moves = res.moves.cpu().numpy()
     costs, stamps = res.trace_cost.cpu().numpy(), res.trace_time.cpu().numpy()
     gaps = []
@@ -128,10 +131,12 @@ def main():
     lo, hi = parallel.shard_range(len(test_set.instances), world, rank)       # this rank's block of instances
     mine = test_set.instances[lo:hi]
     records, gaps = [], []
+    block = chunk * max(args.per_batch_budget, 1)
+    budget = 'per_batch' if args.per_batch_budget > 1 else 'per_instance'
     with tqdm.tqdm(total=len(mine), disable=rank != 0) as pbar:
-        for start in range(0, len(mine), chunk):
-            names = mine[start:start + chunk]
-            rec, g = solve_block(names, test_set, model, scalers, args, chunk)
+        for start in range(0, len(mine), block):
+            names = mine[start:start + block]
+            rec, g = solve_block(names, test_set, model, scalers, args, chunk, budget)
             records += rec
             gaps += g
             pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})

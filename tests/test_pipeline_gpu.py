@@ -58,6 +58,27 @@ def test_solve_batch_chunking_and_weight_guide(model):
         pipeline.solve_batch(D, guides=("regret_pred",))
     with pytest.raises(ValueError):
         pipeline.solve_batch(D, guides=("width",))
+    with pytest.raises(ValueError):
+        pipeline.solve_batch(D, guides=("weight",), budget="per_gpu")
+
+
+def test_budget_policies():
+    """per_instance: every round gets the full time limit (test.py:64,92); per_batch: the rounds share it."""
+    import time
+    from gnngls_amd import pipeline
+    from gnngls_amd.synthetic import random_instances
+    n, B = 20, 12
+    D = torch.from_numpy(random_instances(np.random.default_rng(6), B, n)[0]).cuda()
+    pipeline.solve_batch(D[:4], guides=("weight",), time_limit=0.05, chunk=4)          # warm-up (module load)
+    t0 = time.time()
+    a = pipeline.solve_batch(D, guides=("weight",), time_limit=0.6, chunk=4, budget="per_instance")
+    t1 = time.time()
+    b = pipeline.solve_batch(D, guides=("weight",), time_limit=0.6, chunk=4, budget="per_batch")
+    t2 = time.time()
+    assert a.timing["chunks"] == b.timing["chunks"] == 3
+    assert 1.8 <= t1 - t0 < 2.6 and 0.55 <= t2 - t1 < 1.2
+    assert b.outer_iters.float().mean() < 0.6 * a.outer_iters.float().mean()
+    assert (b.best_cost <= b.init_cost).all() and (a.best_cost <= b.best_cost + 1e-9).float().mean() > 0.5
 
 
 @pytest.mark.parametrize("n,B", [(100, 8), (200, 2)])
