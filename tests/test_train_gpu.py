@@ -296,3 +296,45 @@ def test_whole_step_hip_graph_replay_matches_eager():
         replay_losses.append(static_loss.item())
     assert replay_losses == eager_losses[3:5]
     assert int(model.batch_norms()[0].num_batches_tracked) == 5
+
+
+def test_two_input_features_and_bce_target():
+    """in_dim = 2 (TSPDataset keeps every feature column that is not dropped, datasets.py:86) and the in_solution target
+    with BCEWithLogitsLoss(pos_weight) (train.py:109-112): forward and every gradient against the fp64 oracle."""
+    from gnngls_amd.models import EdgePropertyPredictionModel, LineGraph
+    from oracle import model_oracle as mo
+    n, B = 9, 3
+    N = n * (n - 1) // 2
+    torch.manual_seed(5)
+    oracle = mo.EdgeRegretModelOracle(2, 128, 1, 3, n_heads=8)
+    sd = mo.synthetic_state_dict(oracle, seed=6)
+    oracle.load_state_dict(sd)
+    oracle64 = copy.deepcopy(oracle).double()
+    model = EdgePropertyPredictionModel(2, 128, 1, 3, n_heads=8)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.random((B * N, 2)).astype(np.float32))
+    y = torch.from_numpy((rng.random((B * N, 1)) < 0.2).astype(np.float32))
+    pos_weight = len(y) / y.sum() - 1
+    G = mo.batch_line_graphs(n, B)
+    _, loss64, g64, _ = mo.train_step_reference(oracle64, G, x.double(), y.double(),
+                                                torch.nn.BCEWithLogitsLoss(pos_weight=pos_weight.double()))
+    _, loss32, g32, _ = mo.train_step_reference(oracle, G, x, y, torch.nn.BCEWithLogitsLoss(pos_weight=pos_weight))
+    _, loss, grads, _ = hip_step(model, n, B, x, y, torch.nn.BCEWithLogitsLoss(pos_weight=pos_weight.cuda()))
+    assert abs(loss - loss64.item()) <= 1e-5 * loss64.item() + 3 * abs(loss32.item() - loss64.item())
+    rel32 = max((g32[k].double() - v).abs().max().item() / v.abs().max().item() for k, v in g64.items() if v.abs().max() > 1e-9)
+    for k, v in g64.items():
+        m = v.abs().max().item()
+        if m <= 1e-9:
+            continue
+        e = (grads[k].double() - v).abs().max().item()
+        e32 = (g32[k].double() - v).abs().max().item()
+        assert e <= 3 * e32 + 2e-5 * m or e / m <= 3 * rel32, (k, e, e32, m)
+    assert grads["embed_layer.weight"].shape == (128, 2)
+    # eval-mode forward with two input features
+    model.eval(); oracle64.eval()
+    with torch.no_grad():
+        yh = model(LineGraph(n, batch=B).to("cuda"), x.cuda()).cpu().double()
+        yo = oracle64(G, x.double())
+    assert_pred_close(yh.numpy(), yo.numpy(), rtol=2e-5)
