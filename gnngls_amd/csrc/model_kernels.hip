@@ -244,7 +244,9 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
     float *ftS = reinterpret_cast<float *>(smem);            // [ns][LDF]
     float *elS = ftS + (size_t)ns * LDF;                     // [ns][8]
     float *erS = elS + (size_t)ns * kH;                      // [ns][8]
-    float *top = erS + (size_t)ns * kH;                      // [8][4]: max1, max2, argmax1 (int bits), unused
+    float *eaS = erS + (size_t)ns * kH;                      // [ns][8] exp(el - max1)            } factorised softmax weights,
+    float *ebS = eaS + (size_t)ns * kH;                      // [ns][8] exp(0.2 (el - max1))      } see the aggregation loop
+    float *top = ebS + (size_t)ns * kH;                      // [8][4]: max1, max2, argmax1 (int bits), direct-path flag
     int *nodeS = reinterpret_cast<int *>(top + kH * 4);      // [ns] global node id of slot
 
     const float *ftb = ft + (size_t)b * N * kD;
@@ -253,10 +255,21 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
         nodeS[s] = k < i ? pair_index(k, i, n) : pair_index(i, k, n);
     }
     __syncthreads();
-    for (int q = tid; q < ns * (kD / 4); q += nthreads) {         // stage ft rows: 32 x 16 B per node, coalesced
-        int s = q >> 5, c = (q & 31) * 4;
-        *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDF + c) =
-            *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[s] * kD + c);
+    // stage ft rows: 32 x 16 B per node, coalesced; the loads of a batch are all issued before the first LDS store (a
+    // thread moves ~7 float4 at n = 100: one global round trip instead of seven)
+    constexpr int SB = 8;
+    for (int q0 = tid; q0 < ns * (kD / 4); q0 += nthreads * SB) {
+        f32x4 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int q = q0 + u * nthreads;
+            if (q < ns * (kD / 4)) v[u] = *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[q >> 5] * kD + (q & 31) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int q = q0 + u * nthreads;
+            if (q < ns * (kD / 4)) *reinterpret_cast<f32x4 *>(ftS + (size_t)(q >> 5) * LDF + (q & 31) * 4) = v[u];
+        }
     }
     __syncthreads();
     for (int q = tid; q < ns * kH; q += nthreads) {               // el / er (GATConv: (feat * attn).sum(-1))
@@ -286,7 +299,16 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
             if (take) { m1 = om1; a1 = oa1; }
             m2 = lo1 > hi2 ? lo1 : hi2;
         }
-        if (l32 == 0) { top[h * 4 + 0] = m1; top[h * 4 + 1] = m2; top[h * 4 + 2] = __int_as_float(a1); }
+        // the factorisation below scales by exp(max1 - max2) for the destination that is itself the arg-max source:
+        // keep the direct evaluation when that could overflow
+        if (l32 == 0) { top[h * 4 + 0] = m1; top[h * 4 + 1] = m2; top[h * 4 + 2] = __int_as_float(a1);
+                        top[h * 4 + 3] = (m1 - m2 > 60.f) ? 1.f : 0.f; }
+    }
+    __syncthreads();
+    for (int q = tid; q < ns * kH; q += nthreads) {
+        const float d = (elS[q] - top[(q & 7) * 4]) * 1.4426950408889634f;
+        eaS[q] = __builtin_amdgcn_exp2f(d);
+        ebS[q] = __builtin_amdgcn_exp2f(kSlope * d);
     }
     __syncthreads();
 
@@ -305,8 +327,9 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
         const int dt = unit / (kH / HU), h0 = (unit % (kH / HU)) * HU;
         const int js = dt * 16 + jl;
         const int jsc = js < ns ? js : ns - 1;
-        float er[HU], mm[HU], nm[HU], ws[HU];
+        float er[HU], mm[HU], nm[HU], ws[HU], cpos[HU], cneg[HU], ner[HU];
         f32x4 acc[HU];
+        bool direct = false;
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = h0 + u;
@@ -316,31 +339,70 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
             nm[u] = -mm[u] * kLog2e;
             ws[u] = 0.f;
             acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // exp(LeakyReLU(el + er) - mm) = exp(el - M) * exp(er + M - mm)              if el + er > 0
+            //                              = exp(0.2 (el - M)) * exp(0.2 (er + M) - mm)  otherwise      (M = max1 of the head)
+            // the source factors are in eaS / ebS, the destination factors are computed here: no v_exp_f32 (quarter rate)
+            // in the inner loop
+            const float t = er[u] + top[h * 4 + 0];
+            cpos[u] = __builtin_amdgcn_exp2f(fminf(t - mm[u], 80.f) * kLog2e);
+            cneg[u] = __builtin_amdgcn_exp2f(fminf(kSlope * t - mm[u], 80.f) * kLog2e);
+            ner[u] = -er[u];
+            direct = direct || top[h * 4 + 3] != 0.f;          // wave-uniform
         }
-        // two source groups (2 x 4 sources) per iteration: 8 independent exp + 8 MFMAs in flight
-        for (int s0 = 0; s0 < ns; s0 += 8) {
-            int sidx[2]; bool live[2];
-            f32x4 e[2];
-            float bv[2][HU];
+        // two source groups (2 x 4 sources) per iteration: 8 independent weights + 8 MFMAs in flight
+        if (!direct) {
+            for (int s0 = 0; s0 < ns; s0 += 8) {
+                int sidx[2]; bool live[2];
+                f32x4 e[2], ea[2], eb[2];
+                float bv[2][HU];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int s = s0 + 4 * g + kq;
-                sidx[g] = s < ns ? s : ns - 1;
-                live[g] = (s < ns) && (s != js);              // no self loop, no padding
-                e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
+                for (int g = 0; g < 2; ++g) {
+                    const int s = s0 + 4 * g + kq;
+                    sidx[g] = s < ns ? s : ns - 1;
+                    live[g] = (s < ns) && (s != js);              // no self loop, no padding
+                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
+                    ea[g] = *reinterpret_cast<const f32x4 *>(eaS + sidx[g] * kH + h0);
+                    eb[g] = *reinterpret_cast<const f32x4 *>(ebS + sidx[g] * kH + h0);
 #pragma unroll
-                for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
+                    for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                    for (int u = 0; u < HU; ++u) {
+                        const float wp = ea[g][u] * cpos[u], wn = eb[g][u] * cneg[u];
+                        float w = e[g][u] > ner[u] ? wp : wn;
+                        w = live[g] ? w : 0.f;
+                        ws[u] += w;
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[g][u], acc[u], 0, 0, 0);
+                    }
+                }
             }
+        } else {
+            for (int s0 = 0; s0 < ns; s0 += 8) {
+                int sidx[2]; bool live[2];
+                f32x4 e[2];
+                float bv[2][HU];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 2; ++g) {
+                    const int s = s0 + 4 * g + kq;
+                    sidx[g] = s < ns ? s : ns - 1;
+                    live[g] = (s < ns) && (s != js);
+                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
 #pragma unroll
-                for (int u = 0; u < HU; ++u) {
-                    float x = e[g][u] + er[u];
-                    x = fmaxf(x, kSlope * x);                                  // LeakyReLU(x) = max(x, 0.2x)
-                    float w = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, nm[u]));
-                    w = live[g] ? w : 0.f;
-                    ws[u] += w;
-                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[g][u], acc[u], 0, 0, 0);
+                    for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                    for (int u = 0; u < HU; ++u) {
+                        float x = e[g][u] + er[u];
+                        x = fmaxf(x, kSlope * x);                                  // LeakyReLU(x) = max(x, 0.2x)
+                        float w = __builtin_amdgcn_exp2f(fmaf(x, kLog2e, nm[u]));
+                        w = live[g] ? w : 0.f;
+                        ws[u] += w;
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[g][u], acc[u], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -630,7 +692,7 @@ static int grid_for(long total, int block, int cap = 256 * 16) {
 
 size_t gat_rows_lds_bytes(int n) {
     size_t ns = (size_t)n - 1;
-    return ns * LDF * 4 + 2 * ns * kH * 4 + kH * 4 * 4 + ns * 4 + 16;
+    return ns * LDF * 4 + 4 * ns * kH * 4 + kH * 4 * 4 + ns * 4 + 16;
 }
 
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st) {

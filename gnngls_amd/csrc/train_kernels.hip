@@ -316,28 +316,49 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
         nodeS[s] = k < u ? tri_index(k, u, n) : tri_index(u, k, n);
     }
     __syncthreads();
-    for (int q = tid; q < ns * (CW / 4); q += kGatBwdThreads) {
-        const int s = q / (CW / 4), c = (q % (CW / 4)) * 4;
-        const size_t row = (base + nodeS[s]) * kD + c0 + c;
-        *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(ft + row);
-        *reinterpret_cast<f32x4 *>(dgS + (size_t)s * LDG + c) = *reinterpret_cast<const f32x4 *>(dout + row);
+    // (the global loads of a batch are all issued before the first LDS store: one round trip per batch, not per row)
+    constexpr int SB = 4;
+    for (int q0 = tid; q0 < ns * (CW / 4); q0 += kGatBwdThreads * SB) {
+        f32x4 vf[SB], vd[SB];
+#pragma unroll
+        for (int u2 = 0; u2 < SB; ++u2) {
+            const int q = q0 + u2 * kGatBwdThreads;
+            if (q < ns * (CW / 4)) {
+                const size_t row = (base + nodeS[q / (CW / 4)]) * kD + c0 + (q % (CW / 4)) * 4;
+                vf[u2] = *reinterpret_cast<const f32x4 *>(ft + row);
+                vd[u2] = *reinterpret_cast<const f32x4 *>(dout + row);
+            }
+        }
+#pragma unroll
+        for (int u2 = 0; u2 < SB; ++u2) {
+            const int q = q0 + u2 * kGatBwdThreads;
+            if (q < ns * (CW / 4)) {
+                const int s = q / (CW / 4), c = (q % (CW / 4)) * 4;
+                *reinterpret_cast<f32x4 *>(ftS + (size_t)s * LDG + c) = vf[u2];
+                *reinterpret_cast<f32x4 *>(dgS + (size_t)s * LDG + c) = vd[u2];
+            }
+        }
     }
     __syncthreads();
     for (int q = tid; q < ns * HG; q += kGatBwdThreads) {
         const int s = q / HG, hl = q % HG, hh = grp * HG + hl;
         const float *f = ftS + (size_t)s * LDG + hl * kF;
         const float *d = dgS + (size_t)s * LDG + hl * kF;
-        const float *go = gout + (base + nodeS[s]) * kD + hh * kF;
+        const float *gop = gout + (base + nodeS[s]) * kD + hh * kF;
+        const float *a = att + (base + nodeS[s]) * (2 * kH);
+        f32x4 go4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) go4[v] = *reinterpret_cast<const f32x4 *>(gop + 4 * v);
+        const float a_max = a[hh], a_zinv = a[kH + hh];
         float l = 0.f, r = 0.f, c = 0.f;
 #pragma unroll
         for (int v = 0; v < kF; ++v) {
             l = fmaf(f[v], attn_l[hh * kF + v], l);
             r = fmaf(f[v], attn_r[hh * kF + v], r);
-            c = fmaf(d[v], go[v], c);
+            c = fmaf(d[v], go4[v >> 2][v & 3], c);
         }
-        const float *a = att + (base + nodeS[s]) * (2 * kH);
         elS[q] = l;
-        stS[q] = f32x4{r, -a[hh] * kLog2e, a[kH + hh], c};
+        stS[q] = f32x4{r, -a_max * kLog2e, a_zinv, c};
     }
     __syncthreads();
 

@@ -133,3 +133,32 @@ def test_pack_unpack_scalers():
     iu = np.triu_indices(n, 1)
     expect = np.maximum(g["scaler_inv"].reshape(-1).astype(np.float64), 0)
     assert np.array_equal(R[iu], expect) and np.array_equal(R, R.T) and (np.diag(R) == 0).all()
+
+
+@pytest.mark.parametrize("scale", [8.0, 300.0])
+def test_forward_with_saturated_attention(scale):
+    """Large attention logits: the factorised softmax weights of gat_rows_kernel (exp(el - M) * exp(er + M - max)) must
+    neither overflow nor lose the result, and beyond a logit gap of 60 the kernel takes its direct-evaluation path."""
+    import copy
+    from gnngls_amd.models import EdgePropertyPredictionModel, LineGraph
+    from oracle import model_oracle as mo
+    _, oracle, sd = make_models()
+    sd = dict(sd)
+    for layer in (0, 3):
+        sd[f"message_passing_layers.{layer}.message_passing.module.attn_l"] = \
+            sd[f"message_passing_layers.{layer}.message_passing.module.attn_l"] * scale
+    oracle.load_state_dict(sd)
+    oracle64 = copy.deepcopy(oracle).double().eval()
+    model = EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+    model.load_state_dict(sd)
+    model.eval().to("cuda")
+    n = 23
+    G = mo.line_graph_networkx(n)
+    x = torch.rand(G.number_of_nodes(), 1)
+    with torch.no_grad():
+        y = model(LineGraph(n).to("cuda"), x.cuda()).cpu().double().numpy().reshape(-1)
+        ref64 = oracle64(G, x.double()).numpy().reshape(-1)
+        ref32 = oracle.eval()(G, x).double().numpy().reshape(-1)
+    assert np.isfinite(y).all()
+    err, own = np.abs(y - ref64), np.abs(ref32 - ref64).max()
+    assert (err <= RTOL * np.abs(ref64) + RTOL * np.abs(ref64).max()).all() or err.max() <= 3.0 * own, (err.max(), own)
