@@ -272,13 +272,26 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
         }
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += nthreads) {               // el / er (GATConv: (feat * attn).sum(-1))
-        int s = q >> 3, h = q & 7;
-        const float *f = ftS + (size_t)s * LDF + h * kF;
-        float l = 0.f, r = 0.f;
+    {   // el / er (GATConv: (feat * attn).sum(-1)); the head of a thread is fixed (the stride is a multiple of 8): its
+        // attention vectors live in registers, the ft slice comes in as four ds_read_b128
+        const int h = tid & 7;
+        f32x4 al[4], ar[4];
 #pragma unroll
-        for (int u = 0; u < kF; ++u) { l = fmaf(f[u], attn_l[h * kF + u], l); r = fmaf(f[u], attn_r[h * kF + u], r); }
-        elS[q] = l; erS[q] = r;
+        for (int v = 0; v < 4; ++v) {
+            al[v] = *reinterpret_cast<const f32x4 *>(attn_l + h * kF + 4 * v);
+            ar[v] = *reinterpret_cast<const f32x4 *>(attn_r + h * kF + 4 * v);
+        }
+        for (int q = tid; q < ns * kH; q += nthreads) {
+            const float *f = ftS + (size_t)(q >> 3) * LDF + h * kF;
+            float l = 0.f, r = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 fv = *reinterpret_cast<const f32x4 *>(f + 4 * v);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { l = fmaf(fv[u], al[v][u], l); r = fmaf(fv[u], ar[v][u], r); }
+            }
+            elS[q] = l; erS[q] = r;
+        }
     }
     __syncthreads();
     if (tid < 256) {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles

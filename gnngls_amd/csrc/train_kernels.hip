@@ -340,25 +340,39 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
         }
     }
     __syncthreads();
-    for (int q = tid; q < ns * HG; q += kGatBwdThreads) {
-        const int s = q / HG, hl = q % HG, hh = grp * HG + hl;
-        const float *f = ftS + (size_t)s * LDG + hl * kF;
-        const float *d = dgS + (size_t)s * LDG + hl * kF;
-        const float *gop = gout + (base + nodeS[s]) * kD + hh * kF;
-        const float *a = att + (base + nodeS[s]) * (2 * kH);
-        f32x4 go4[4];
+    {   // el, er and c = <dOut, out> per (slot, head); a thread's head is fixed (the stride is a multiple of HG)
+        const int hl = tid % HG, hh = grp * HG + hl;
+        f32x4 al[4], ar[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) go4[v] = *reinterpret_cast<const f32x4 *>(gop + 4 * v);
-        const float a_max = a[hh], a_zinv = a[kH + hh];
-        float l = 0.f, r = 0.f, c = 0.f;
-#pragma unroll
-        for (int v = 0; v < kF; ++v) {
-            l = fmaf(f[v], attn_l[hh * kF + v], l);
-            r = fmaf(f[v], attn_r[hh * kF + v], r);
-            c = fmaf(d[v], go4[v >> 2][v & 3], c);
+        for (int v = 0; v < 4; ++v) {
+            al[v] = *reinterpret_cast<const f32x4 *>(attn_l + hh * kF + 4 * v);
+            ar[v] = *reinterpret_cast<const f32x4 *>(attn_r + hh * kF + 4 * v);
         }
-        elS[q] = l;
-        stS[q] = f32x4{r, -a_max * kLog2e, a_zinv, c};
+        for (int q = tid; q < ns * HG; q += kGatBwdThreads) {
+            const int s = q / HG;
+            const float *f = ftS + (size_t)s * LDG + hl * kF;
+            const float *d = dgS + (size_t)s * LDG + hl * kF;
+            const float *gop = gout + (base + nodeS[s]) * kD + hh * kF;
+            const float *a = att + (base + nodeS[s]) * (2 * kH);
+            f32x4 go4[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) go4[v] = *reinterpret_cast<const f32x4 *>(gop + 4 * v);
+            const float a_max = a[hh], a_zinv = a[kH + hh];
+            float l = 0.f, r = 0.f, c = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 fv = *reinterpret_cast<const f32x4 *>(f + 4 * v);
+                const f32x4 dv = *reinterpret_cast<const f32x4 *>(d + 4 * v);
+#pragma unroll
+                for (int u2 = 0; u2 < 4; ++u2) {
+                    l = fmaf(fv[u2], al[v][u2], l);
+                    r = fmaf(fv[u2], ar[v][u2], r);
+                    c = fmaf(dv[u2], go4[v][u2], c);
+                }
+            }
+            elS[q] = l;
+            stS[q] = f32x4{r, -a_max * kLog2e, a_zinv, c};
+        }
     }
     __syncthreads();
 
