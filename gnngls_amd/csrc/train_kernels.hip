@@ -282,7 +282,8 @@ __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over
     return v;
 }
 
-// (Measured and rejected: taking the source tiles two at a time with both T chains issued ahead of the arithmetic, and
+// (Measured and rejected: the factorised exponentials of gat_rows_kernel here, with its wave-uniform direct-path branch in
+// the unrolled tile loop: 3.3 -> 4.0 ms per step; taking the source tiles two at a time with both T chains issued ahead of the arithmetic, and
 // skipping the self-loop mask on interior tiles -- 3.4 -> 3.6 ms per step at TSP100 x 32, more registers, no gain.)
 // Workgroup = (instance b, TSP row u, head group); wave w owns head h = group * kGatBwdHeads + w.  Outer loop:
 // destination tiles dt (dOut fragments, softmax statistics and the B fragments of the second product are fetched once
