@@ -763,11 +763,17 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    // units = (16-destination tiles) x (2 head quads); the wave count that needs the fewest rounds, fewest waves on ties
+    // units = (16-destination tiles) x (2 head quads), spread over 4..8 waves: the wave count with the fewest idle wave
+    // slots; on ties the one that brings the CU closest to 16 resident waves at the LDS-limited workgroup count
     const int units = ((n - 1 + 15) / 16) * 2;
+    const int wgs_per_cu = (int)((size_t)160 * 1024 / lds) > 0 ? (int)((size_t)160 * 1024 / lds) : 1;
+    const int want = 16 / wgs_per_cu;
     int waves = 4;
-    for (int w = 5; w <= 8; ++w)
-        if ((units + w - 1) / w < (units + waves - 1) / waves) waves = w;
+    for (int w = 5; w <= 8; ++w) {
+        const int idle_w = (units + w - 1) / w * w - units, idle_b = (units + waves - 1) / waves * waves - units;
+        const int dw = w > want ? w - want : want - w, db = waves > want ? waves - want : want - waves;
+        if (idle_w < idle_b || (idle_w == idle_b && dw < db)) waves = w;
+    }
     hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(64 * waves), lds, st, ft, attn_l, attn_r, n, part, part_ms);
     return hipGetLastError();
 }
