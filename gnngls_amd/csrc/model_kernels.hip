@@ -84,9 +84,23 @@ __global__ void unpack_regret_kernel(const float *y, int B, int n, double scale,
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_kernel(const float *x, const float *W, const float *bias, float *h, long M, int in_dim) {
     const long total = M * (kD / 4);
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        long m = q / (kD / 4);
-        int c = (int)(q % (kD / 4)) * 4;
+    const long stride = (long)gridDim.x * blockDim.x;          // a multiple of 32: the 4 columns of a thread never change
+    const long q0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)(q0 % (kD / 4)) * 4;
+    if (in_dim == 1) {                                          // the reference's feature set (datasets.py:14-20)
+        const f32x4 w = f32x4{W[c], W[c + 1], W[c + 2], W[c + 3]};
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias + c);
+        for (long q = q0; q < total; q += stride) {
+            const float xv = x[q / (kD / 4)];
+            f32x4 acc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(xv, w[u], 0.f) + bb[u];
+            *reinterpret_cast<f32x4 *>(h + q * 4) = acc;
+        }
+        return;
+    }
+    for (long q = q0; q < total; q += stride) {
+        const long m = q / (kD / 4);
         f32x4 acc;
         for (int u = 0; u < 4; ++u) {
             float a = 0.f;
