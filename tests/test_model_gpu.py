@@ -81,7 +81,9 @@ def test_forward_batch_vs_oracle(n, B):
             ref_err = np.abs(ref32 - ref64).max()
             assert (err <= bound).all() or err.max() <= 3.0 * ref_err, \
                 f"n={n} b={b}: max err {err.max():.3e} (bound {bound.min():.3e}); fp32 reference's own error {ref_err:.3e}"
-            if n >= 5:      # and directly against the fp32 reference path, the form the north star states
+            # and directly against the fp32 reference path, the form the north star states -- wherever that path is itself
+            # a usable yardstick (its own rounding error well inside the bar; not so for some tiny ill-conditioned graphs)
+            if n >= 5 and ref_err <= 0.5 * RTOL * np.abs(ref64).max():
                 err32 = np.abs(y[b] - ref32)
                 assert (err32 <= RTOL * np.abs(ref32) + RTOL * np.abs(ref32).max()).all(), \
                     f"n={n} b={b}: max |hip - fp32 reference| {err32.max():.3e}"
