@@ -513,6 +513,9 @@ __device__ __forceinline__ void ffn_gemm2_stage(f32x4 (&accY)[8], const f32x4 (&
     }
 }
 
+// (Measured and rejected, r01i: a mapping where a wave owns 32 rows x one half of the hidden tiles, so each weight fragment
+// read from LDS feeds two row tiles -- 41 % fewer ds_read_b128, partial outputs exchanged once in the epilogue: 196 VGPRs,
+// 11.5 ms vs 11.1 ms per 1024 TSP100 instances.  LDS fragment traffic is not what holds this kernel at 75 % of the MFMA peak.)
 // Modes.  FFN_INFER: as above.  FFN_TRAIN_FWD: the x tile is BN1 applied to an already merged h1 = h + GATConv(h) passed
 // in `hin` (part / part_ms unused; the batch statistics of h1 must be known before BN1 can be applied) and the hidden
 // activations ReLU(W1 x + b1) are also written to `hid_out` [M,512] for the backward.  FFN_BWD: the SAME two chained
