@@ -3,7 +3,7 @@
 tests/test_gls_fuzz_gpu.py with a different master seed, more cases and longer runs).  Every accepted move, the best
 tour, its cost and the final penalties must match bit for bit.
 
-    python scripts/fuzz_campaign.py [--cases 400] [--seed 1] [--max_k 30]
+    python scripts/fuzz_campaign.py [--cases 400] [--seed 1] [--max_k 30] [--min_n 4] [--max_n 130]
 """
 import argparse
 import os
@@ -26,11 +26,13 @@ def main():
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max_k", type=int, default=30)
+    ap.add_argument("--min_n", type=int, default=4)
+    ap.add_argument("--max_n", type=int, default=130)
     args = ap.parse_args()
     master = np.random.default_rng(args.seed)
     bad, moves, t0 = [], 0, time.time()
     for ci in range(args.cases):
-        c = dict(n=int(master.integers(4, 131)), kind=str(master.choice(["euclid", "lattice", "noisy"])),
+        c = dict(n=int(master.integers(args.min_n, args.max_n + 1)), kind=str(master.choice(["euclid", "lattice", "noisy"])),
                  pm=int(master.choice([1, 5, 20, 30])), fi=bool(master.integers(0, 2)), K=int(master.integers(1, args.max_k + 1)),
                  bits=int(master.choice([0, 16, 32, -1])), guides=int(master.integers(1, 3)), seed=int(master.integers(1 << 30)))
         rng = np.random.default_rng(c["seed"])
