@@ -312,6 +312,33 @@ def test_full_size_batch_properties(ops):
     assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("n,B,limit", [(30, 12, 0.2), (100, 8, 0.3)])
+def test_wall_clock_run_equals_the_oracle_at_the_same_iteration_count(n, B, limit):
+    """The headline mode (deadline instead of an iteration count, algorithms.py:146): whatever number of outer iterations
+    an instance completed before the deadline, its best tour and cost are bit for bit what the CPU oracle returns for
+    exactly that many iterations (trace-free throughput path, per-move tour_cost deferred)."""
+    from gnngls_amd import ops
+    from oracle import gls_oracle as go
+    D, _ = random_instances(np.random.default_rng(77 + n), B, n)
+    d = dev(D, torch.float64)
+    rng = np.random.default_rng(5)
+    guide = np.maximum(rng.normal(0.0, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)    # zero-heavy, like
+    guide = np.triu(guide, 1) + np.transpose(np.triu(guide, 1), (0, 2, 1))                              # clamped regrets
+    g = dev(np.stack([guide, D]), torch.float64)
+    init = ops.nearest_neighbor(g[0].contiguous())
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=limit)
+    torch.cuda.synchronize()
+    iters = r.outer_iters.cpu().numpy()
+    assert (r.status == 0).all() and (iters > 10).all()
+    init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
+    for b in range(B):
+        o = go.guided_local_search(D[b], np.stack([guide[b], D[b]]), init_h[b], cost_h[b], perturbation_moves=20,
+                                   max_outer_iters=int(iters[b]), trace_cap=1, want_penalty=False)
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"], (b, int(iters[b]))
+        assert_bits(r.best_cost[b].item(), o["best_cost"])
+
+
 @pytest.mark.parametrize("n,B,K,min_optimal,max_mean_gap", [(14, 32, 200, 0.95, 0.05), (20, 16, 400, 0.75, 0.5)])
 def test_search_against_exact_optimum(n, B, K, min_optimal, max_mean_gap):
     """The true optimality gap (test.py:104) on instances small enough for the Held-Karp DP (oracle/held_karp.c): no
