@@ -30,6 +30,7 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream -------------------
+// (measurement hook for bench.py: process-global and not thread-safe; off unless gnngls_profile_enable(1) was called)
 struct ProfSpan { int kind; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfSpan> g_spans;

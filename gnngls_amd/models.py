@@ -239,6 +239,9 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         L = _lib.load()
+        if ctx.ws is None:
+            raise RuntimeError("the activations of this training forward were consumed by its first backward "
+                               "(the hidden activations are overwritten in place): retain_graph is not supported")
         x, image = ctx.saved_tensors
         B, n, in_dim, n_layers = ctx.model_dims
         grads = torch.empty_like(image)

@@ -189,6 +189,11 @@ def test_forward_workspace_is_owned_by_the_autograd_node():
     torch.nn.functional.mse_loss(y1, t).backward()
     for a, b in zip(single, [p.grad for p in model.parameters()]):
         assert torch.equal(a, b)                 # the backward is deterministic (fixed-order reductions)
+    # a second backward through the same node has nothing to differentiate with: loud error, not stale numbers
+    loss = torch.nn.functional.mse_loss(model(G, x1), t)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="consumed"):
+        loss.backward()
 
 
 def test_adam_steps_track_the_oracle():
