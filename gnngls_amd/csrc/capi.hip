@@ -491,10 +491,10 @@ int gnngls_regret_train_backward(const float *feat, const float *params, const f
           GNNGLS_TRY(gnngls::launch_colsum(gnngls::CS_SUM_PROD, w.DA, h3, nullptr, M, 128, 0, w.CSP, &nb, st));
           GNNGLS_TRY(gnngls::launch_bn_bwd_finalize(w.CSP, nb, M, bn2_g, bn + 4 * 128, bn + 5 * 128, d_bn2_g, d_bn2_b, w.COEF, st)); }
         { ProfScope ps(GNNGLS_PROF_TRAIN_ELEMENTWISE, st);
-          GNNGLS_TRY(gnngls::launch_bn_bwd_apply(w.DA, h3, bn + 4 * 128, w.COEF, w.DB, M, st));
-          GNNGLS_TRY(gnngls::launch_affine_cols(h1, bn + 2 * 128, bn + 3 * 128, w.X2, M, st));         // x = BN1(h1), recomputed
-          GNNGLS_TRY(gnngls::launch_transpose(w2, 128, 512, w.WT, st));                                // W2^T [512,128]
-          GNNGLS_TRY(gnngls::launch_transpose(w1, 512, 128, w.WT + 512 * 128, st)); }                  // W1^T [128,512]
+          // d h3 = BatchNorm-2 backward of DA, and x = BN1(h1) recomputed, in one elementwise pass
+          GNNGLS_TRY(gnngls::launch_bn_bwd_apply_and_affine(w.DA, h3, bn + 4 * 128, w.COEF, w.DB, h1, bn + 2 * 128, bn + 3 * 128,
+                                                            w.X2, M, st));
+          GNNGLS_TRY(gnngls::launch_transpose_pair(w2, w1, w.WT, w.WT + 512 * 128, st)); }              // W2^T, W1^T
         // feed-forward block backward (models.py:28-33): h3 = x + W2 relu(W1 x + b1) + b2
         float *hid = w.HID + 4 * row * l;                    // saved ReLU(W1 x + b1)
         { ProfScope ps(GNNGLS_PROF_TRAIN_GEMM_TN, st);

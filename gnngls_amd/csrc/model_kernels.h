@@ -21,7 +21,7 @@ hipError_t launch_ffn_fused_train(const float *h1, const float *bn1_s, const flo
                                   float *hidden, long M, hipStream_t st);
 hipError_t launch_ffn_fused_bwd(const float *dh3, const float *W2T, const float *W1T, const float *ones, const float *zeros,
                                 float *dx, float *hidden, long M, hipStream_t st);
-hipError_t launch_transpose(const float *src, int R, int C, float *dst, hipStream_t st);
+hipError_t launch_transpose_pair(const float *W2, const float *W1, float *W2T, float *W1T, hipStream_t st);
 hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
                            float *part_ms, hipStream_t st);
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,

@@ -835,18 +835,25 @@ hipError_t launch_ffn_fused_bwd(const float *dh3, const float *W2T, const float 
                                     hidden, st);
 }
 
-// dst[C,R] = src[R,C]^T (weight matrices, 64K elements)
-__global__ void transpose_kernel(const float *__restrict__ src, int R, int C, float *__restrict__ dst) {
+// The two weight transposes the FFN backward needs, one launch: z = 0: dst0[512,128] = W2[128,512]^T, z = 1:
+// dst1[128,512] = W1[512,128]^T (64K elements each; both are 16 x 4 grids of 32 x 32 tiles)
+__global__ void transpose_pair_kernel(const float *__restrict__ W2, const float *__restrict__ W1, float *__restrict__ W2T,
+                                      float *__restrict__ W1T) {
     __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const bool second = blockIdx.z != 0;
+    const float *src = second ? W1 : W2;
+    float *dst = second ? W1T : W2T;
+    const int R = second ? 512 : 128, C = second ? 128 : 512;
+    const int tiles_c = C / 32, tile_id = blockIdx.x;                // 64 tiles per matrix
+    const int c0 = (tile_id % tiles_c) * 32, r0 = (tile_id / tiles_c) * 32;
     for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = src[(long)(r0 + i) * C + c0 + threadIdx.x];
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += 8) dst[(long)(c0 + i) * R + r0 + threadIdx.x] = tile[threadIdx.x][i];
 }
 
-hipError_t launch_transpose(const float *src, int R, int C, float *dst, hipStream_t st) {
+hipError_t launch_transpose_pair(const float *W2, const float *W1, float *W2T, float *W1T, hipStream_t st) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(transpose_kernel, dim3(C / 32, R / 32), dim3(32, 8), 0, st, src, R, C, dst);
+    hipLaunchKernelGGL(transpose_pair_kernel, dim3(64, 1, 2), dim3(32, 8), 0, st, W2, W1, W2T, W1T);
     return hipGetLastError();
 }
 

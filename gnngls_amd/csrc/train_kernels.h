@@ -22,6 +22,9 @@ hipError_t launch_bn_bwd_finalize(const double *partial, int nblocks, long M, co
                                   const float *invstd, float *dgamma, float *dbeta, float *coef, hipStream_t st);
 hipError_t launch_bn_bwd_apply(const float *dy, const float *x, const float *mean, const float *coef, float *dx, long M,
                                hipStream_t st);
+hipError_t launch_bn_bwd_apply_and_affine(const float *dy, const float *h3, const float *mean, const float *coef, float *dx,
+                                          const float *h1, const float *scale, const float *shift, float *xout, long M,
+                                          hipStream_t st);
 hipError_t launch_affine_cols(const float *x, const float *scale, const float *shift, float *out, long M, hipStream_t st);
 hipError_t launch_outer_rows(const float *dy, const float *w, float *dh, long M, hipStream_t st);
 hipError_t launch_gat_combine_train(const float *part, const float *part_ms, const float *h, long M, float *g, float *h1,

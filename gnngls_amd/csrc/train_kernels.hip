@@ -198,6 +198,30 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
     }
 }
 
+// The two elementwise passes that open a layer's backward, one launch: d h3 = BatchNorm-2 backward of dy (as
+// bn_bwd_apply_kernel) and x = BatchNorm-1 applied to h1 (as affine_cols_kernel), both [M,128]
+__global__ void bn_bwd_apply_and_affine_kernel(const float *__restrict__ dy, const float *__restrict__ h3,
+                                               const float *__restrict__ mean, const float *__restrict__ coef,
+                                               float *__restrict__ dx, const float *__restrict__ h1,
+                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                               float *__restrict__ xout, long M) {
+    const long total = M * (kD / 4);
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(q & 31) * 4;
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(dy + q * 4);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(h3 + q * 4);
+        const f32x4 hv = *reinterpret_cast<const f32x4 *>(h1 + q * 4);
+        f32x4 o, x2;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            o[v] = coef[c + v] * d[v] + coef[kD + c + v] * (xv[v] - mean[c + v]) + coef[2 * kD + c + v];
+            x2[v] = hv[v] * scale[c + v] + shift[c + v];
+        }
+        *reinterpret_cast<f32x4 *>(dx + q * 4) = o;
+        *reinterpret_cast<f32x4 *>(xout + q * 4) = x2;
+    }
+}
+
 // out = x * scale[c] + shift[c]   (BatchNorm apply with precomputed affine)
 __global__ void affine_cols_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
                                    float *__restrict__ out, long M) {
@@ -641,6 +665,15 @@ hipError_t launch_bn_bwd_apply(const float *dy, const float *x, const float *mea
                                hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M)), dim3(256), 0, st, dy, x, mean, coef, dx, M);
+    return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd_apply_and_affine(const float *dy, const float *h3, const float *mean, const float *coef, float *dx,
+                                          const float *h1, const float *scale, const float *shift, float *xout, long M,
+                                          hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bn_bwd_apply_and_affine_kernel, dim3(ew_grid(M)), dim3(256), 0, st, dy, h3, mean, coef, dx, h1, scale,
+                       shift, xout, M);
     return hipGetLastError();
 }
 
