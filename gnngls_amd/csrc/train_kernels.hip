@@ -591,20 +591,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
 }
 
 // 256 threads = 64 outputs x 4 chunk groups (4x the loads in flight of a one-thread-per-output sum); the groups meet in LDS
-// in fixed order
+// in fixed order.  Two segments in one launch: the E weight-gradient entries, then (optional) the E2 column sums of X.
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float *__restrict__ partial, int chunks, long E,
-                                                             float *__restrict__ out) {
+                                                             float *__restrict__ out, const float *__restrict__ partial2,
+                                                             long E2, float *__restrict__ out2) {
     __shared__ double red[256];
     const int tid = threadIdx.x, el = tid & 63, part = tid >> 6;
-    const long e = (long)blockIdx.x * 64 + el;
+    long e = (long)blockIdx.x * 64 + el;
+    const float *src = partial;
+    float *dst = out;
+    long width = E;
+    if (e >= E) { e -= (E + 63) / 64 * 64; src = partial2; dst = out2; width = E2; }      // second segment starts on a block boundary
     double s = 0.0;
-    if (e < E) {
+    if (e >= 0 && e < width) {
 #pragma unroll 8
-        for (int k = part; k < chunks; k += 4) s += (double)partial[(size_t)k * E + e];
+        for (int k = part; k < chunks; k += 4) s += (double)src[(size_t)k * width + e];
     }
     red[tid] = s;
     __syncthreads();
-    if (part == 0 && e < E) out[e] = (float)(((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el]);
+    if (part == 0 && e >= 0 && e < width) dst[e] = (float)(((red[el] + red[64 + el]) + red[128 + el]) + red[192 + el]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -739,9 +744,8 @@ hipError_t launch_gemm_tn(const float *X, const float *Y, long M, int N1, int N2
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(chunks, N1 / 128, N2 / 128), dim3(256), 0, st, X, Y, M, N1, N2, rows, partial, xpart);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((E + 63) / 64)), dim3(256), 0, st, partial, chunks, E, out);
-    if (xsum_out)
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((N1 + 63) / 64)), dim3(256), 0, st, xpart, chunks, (long)N1, xsum_out);
+    const unsigned blocks = (unsigned)((E + 63) / 64 + (xsum_out ? (N1 + 63) / 64 : 0));
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, chunks, E, out, xpart, (long)N1, xsum_out);
     return hipGetLastError();
 }
 
