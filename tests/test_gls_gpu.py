@@ -355,3 +355,17 @@ def test_search_against_exact_optimum(n, B, K, min_optimal, max_mean_gap):
     gap = r.best_cost.cpu().numpy() / opt - 1.0
     assert gap.min() >= -1e-12
     assert (gap <= 1e-12).mean() >= min_optimal and gap.mean() * 100 <= max_mean_gap, (gap.mean() * 100, (gap <= 1e-12).mean())
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/gls_from_c.c: the library driven from C with nothing but the HIP runtime (no Python objects, no torch
+    types cross the boundary): compiles with gcc against include/gnngls_hip.h and improves every tour."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "gls_from_c")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "gls_from_c.c"), "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-I" + os.path.join(root, "include"), "-L" + os.path.join(root, "gnngls_amd"),
+                           "-lgnngls_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "gnngls_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.check_output([exe, "40", "32", "50"], text=True)
+    assert "0 anomalies" in out and "32 TSP40 instances" in out, out
