@@ -45,7 +45,8 @@ int main(int argc, char **argv) {
     CHECK_GLS(gnngls_nearest_neighbor(dD, B, n, 0, dinit, NULL));
     CHECK_GLS(gnngls_tour_cost(dinit, dD, B, n, dinit_cost, NULL));
     CHECK_GLS(gnngls_gls_run(dD, dD /* one guide: the weights */, 1, B, n, dinit, dinit_cost, 20, 0, 0, (int64_t)K, 0.0, 60.0,
-                             dbest, dbest_cost, diters, NULL, NULL, 0, NULL, NULL, NULL, dstatus, NULL));
+                             dbest, dbest_cost, diters, NULL, NULL, 0, NULL, NULL, NULL, dstatus,
+                             NULL, NULL, NULL, 0, NULL /* no improvement trace */, NULL));
     CHECK_HIP(hipDeviceSynchronize());
 
     double *c0 = (double *)malloc(B * sizeof(double)), *c1 = (double *)malloc(B * sizeof(double));

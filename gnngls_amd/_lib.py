@@ -26,7 +26,7 @@ SIGNATURES = {
     "gnngls_tour_cost": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_nearest_neighbor": [_vp, _int, _int, _int, _vp, _vp],
     "gnngls_gls_run": [_vp, _vp, _int, _int, _int, _vp, _vp, _int, _int, _int, _i64, _f64, _f64,
-                       _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp],
+                       _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp],
     "gnngls_model_packed_floats": [_int, _int],
     "gnngls_regret_forward_workspace_bytes": [_int, _int],
     "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],

@@ -99,7 +99,7 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
 
 extern "C" {
 
-int gnngls_abi_version(void) { return 1; }
+int gnngls_abi_version(void) { return 2; }
 const char *gnngls_last_error(void) { return g_err; }
 
 int gnngls_gls_resident_capacity(int n) {
@@ -167,10 +167,13 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
                    int64_t max_outer_iters, double time_limit_s, double watchdog_s,
                    int32_t *best_tour, double *best_cost, int64_t *outer_iters,
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
-                   int32_t *penalty_out, int64_t *evals_out, int32_t *status, void *stream) {
+                   int32_t *penalty_out, int64_t *evals_out, int32_t *status,
+                   double *imp_cost, float *imp_time, int64_t *imp_iter, int imp_cap, int32_t *imp_len, void *stream) {
     if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!D || !init_tour || !init_cost || !best_tour || !best_cost || B < 0 || n < 3 || n > 65535 || trace_cap < 0)
         return fail(GNNGLS_ERR_ARG, "gls_run: bad argument");
+    if (imp_cap < 0 || ((imp_cost || imp_time || imp_iter) && !imp_len))
+        return fail(GNNGLS_ERR_ARG, "gls_run: improvement trace needs imp_len and imp_cap >= 0");
     if (max_outer_iters != 0 && (!guides || n_guides < 1))
         return fail(GNNGLS_ERR_ARG, "gls_run: guides required when outer iterations are requested");
     if (!(watchdog_s > 0.0)) return fail(GNNGLS_ERR_ARG, "gls_run: watchdog_s must be > 0");
@@ -186,6 +189,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.best_tour = best_tour; A.best_cost = best_cost; A.outer_iters = (long long *)outer_iters;
     A.trace_cost = trace_cost; A.trace_time = trace_time; A.trace_cap = trace_cost ? trace_cap : 0;
     A.pen16_limit = g_pen16_limit;
+    A.imp_cost = imp_cost; A.imp_time = imp_time; A.imp_iter = (long long *)imp_iter; A.imp_cap = imp_cap; A.imp_len = imp_len;
     A.stamps = g_stamp_buffer;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
     const GlsConfig cfg = gls_config(n, penalty_bits, B);

@@ -30,6 +30,12 @@ struct GlsArgs {
     int32_t *pen_ws;           // global store: [B,n,n] int32; compact store: [B,n(n-1)/2] int32; zeroed by the host
     int pen16_limit;           // 65535 (see gnngls_debug_set_penalty16_limit)
     long long *stamps;         // diagnostic builds (-DGLS_STAMPS) only: [B,8] cycle totals, else unused
+    // improvement trace: one entry whenever the returned best improves (algorithms.py:143,190-191)
+    double *imp_cost;          // [B,imp_cap] or NULL
+    float *imp_time;           // [B,imp_cap] seconds since workgroup start, or NULL
+    long long *imp_iter;       // [B,imp_cap] completed outer iterations at that moment, or NULL
+    int imp_cap;
+    int32_t *imp_len;          // [B] number of improvements (may exceed imp_cap); written by the kernel
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };

@@ -749,8 +749,25 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     int status = 0;
     STAMP_DECL;
 
+    // improvement trace: (cost, device time, completed outer iterations) whenever the returned best improves
+    // (algorithms.py:143,190-191) -- a few hundred entries per run however long it is.  The counter lives in the
+    // output array itself (thread 0 is its only reader and writer): no register, no LDS.
+    auto push_improvement = [&](double c, long long it) {
+        if (!A.imp_len) return;
+        const int l = A.imp_len[b];
+        if (l < A.imp_cap) {
+            const size_t q = (size_t)b * A.imp_cap + l;
+            if (A.imp_cost) A.imp_cost[q] = c;
+            if (A.imp_time) A.imp_time[q] = (float)((double)(wall_clock64() - t_start) * 1e-8);
+            if (A.imp_iter) A.imp_iter[q] = it;
+        }
+        A.imp_len[b] = l + 1;
+    };
+    if (tid == 0 && A.imp_len) A.imp_len[b] = 0;
+
     local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
+    if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
     __syncthreads();
 
@@ -893,6 +910,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
             for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
+            if (tid == 0) push_improvement(best_cost, iter_i + 1);
         }
         iter_i++;
         __syncthreads();
@@ -900,6 +918,16 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
 
     // ---- outputs ----
     for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = (int32_t)bt[p];
+    if (tid == 0 && A.imp_len && A.imp_cap > 0) {
+        // terminal entry (returned best, end of the search, completed iterations): always the last one, and always
+        // stored -- if the improvements overflowed the buffer it takes the last slot
+        const int l = A.imp_len[b];
+        const size_t q = (size_t)b * A.imp_cap + (l < A.imp_cap ? l : A.imp_cap - 1);
+        if (A.imp_cost) A.imp_cost[q] = best_cost;
+        if (A.imp_time) A.imp_time[q] = (float)((double)(wall_clock64() - t_start) * 1e-8);
+        if (A.imp_iter) A.imp_iter[q] = iter_i;
+        A.imp_len[b] = l + 1;
+    }
     if (tid == 0) {
         A.best_cost[b] = best_cost;
         if (A.outer_iters) A.outer_iters[b] = iter_i;

@@ -100,6 +100,16 @@ class GlsResult:
     penalty: torch.Tensor        # [B,n,n] int32 or None
     evals: torch.Tensor          # [B] int64
     status: torch.Tensor         # [B] int32
+    imp_cost: torch.Tensor = None   # [B,imp_cap] fp64: the returned best after every improvement (algorithms.py:143,190-191)
+    imp_time: torch.Tensor = None   # [B,imp_cap] fp32 seconds since the workgroup started
+    imp_iter: torch.Tensor = None   # [B,imp_cap] int64 completed outer iterations at that moment
+    imp_len: torch.Tensor = None    # [B] int32 number of improvements (may exceed imp_cap)
+
+    @property
+    def trace_truncated(self):
+        """[B] bool: more moves were accepted than the per-move trace could hold."""
+        cap = 0 if self.trace_cost is None else self.trace_cost.shape[1]
+        return self.trace_len > cap
 
 
 STATUS_OK, STATUS_WATCHDOG, STATUS_PENALTY_OVERFLOW = 0, 1, 2
@@ -107,13 +117,16 @@ STATUS_OK, STATUS_WATCHDOG, STATUS_PENALTY_OVERFLOW = 0, 1, 2
 
 def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improvement=False,
             max_outer_iters=-1, time_limit_s=0.0, watchdog_s=None, trace_cap=0, want_trace_time=False,
-            want_penalty=False, penalty_bits=0, retry_overflow=True):
+            want_penalty=False, penalty_bits=0, retry_overflow=True, imp_cap=0):
     """guided_local_search (reference algorithms.py:135-195) for a batch of instances.
 
     D [B,n,n] fp64 symmetric, guides [G,B,n,n] fp64 (or None when max_outer_iters == 0 ->
     local_search only), init_tour [B,n+1] int32, init_cost [B] fp64.
     penalty_bits: 0 = auto (see include/gnngls_hip.h).  With retry_overflow (default) instances whose
-    16-bit penalty counters overflowed are rerun with 32-bit counters (needs a host sync)."""
+    16-bit penalty counters overflowed are rerun with 32-bit counters (needs a host sync).
+    imp_cap > 0 records the improvement trace (bounded however long the run is; see include/gnngls_hip.h).
+    watchdog_s: None = time_limit_s + 5 s in wall-clock mode; in iteration-count mode a bound that scales with the
+    requested work (the caller asked for exactly that many iterations, so the watchdog only catches hangs)."""
     B, n = _check_shapes(init_tour, D)
     dev = D.device
     G = 0
@@ -122,7 +135,8 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         G = guides.shape[0]
     assert init_cost.dtype == torch.float64 and init_cost.shape == (B,)
     if watchdog_s is None:
-        watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 60.0
+        # iteration-count mode: ~n^2 evaluations per descent pass, tens of passes per outer iteration
+        watchdog_s = (time_limit_s + 5.0) if max_outer_iters < 0 else 60.0 + 1e-7 * n * n * max(max_outer_iters, 1)
     best_tour = torch.empty_like(init_tour)
     best_cost = torch.empty((B,), dtype=torch.float64, device=dev)
     outer = torch.zeros((B,), dtype=torch.int64, device=dev)
@@ -132,6 +146,10 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
     penalty = torch.zeros((B, n, n), dtype=torch.int32, device=dev) if want_penalty else None
     evals = torch.zeros((B,), dtype=torch.int64, device=dev)
     status = torch.zeros((B,), dtype=torch.int32, device=dev)
+    imp_cost = torch.zeros((B, imp_cap), dtype=torch.float64, device=dev) if imp_cap > 0 else None
+    imp_time = torch.zeros((B, imp_cap), dtype=torch.float32, device=dev) if imp_cap > 0 else None
+    imp_iter = torch.zeros((B, imp_cap), dtype=torch.int64, device=dev) if imp_cap > 0 else None
+    imp_len = torch.zeros((B,), dtype=torch.int32, device=dev) if imp_cap > 0 else None
     L = _lib.load()
     _lib.check(L.gnngls_gls_run(
         _lib.ptr(D), _lib.ptr(guides), G, B, n, _lib.ptr(init_tour), _lib.ptr(init_cost),
@@ -139,17 +157,20 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         float(time_limit_s), float(watchdog_s),
         _lib.ptr(best_tour), _lib.ptr(best_cost), _lib.ptr(outer),
         _lib.ptr(trace_cost), _lib.ptr(trace_time), int(trace_cap), _lib.ptr(trace_len),
-        _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status), _lib.current_stream()), "gls_run")
-    res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status)
+        _lib.ptr(penalty), _lib.ptr(evals), _lib.ptr(status),
+        _lib.ptr(imp_cost), _lib.ptr(imp_time), _lib.ptr(imp_iter), int(imp_cap), _lib.ptr(imp_len),
+        _lib.current_stream()), "gls_run")
+    res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status,
+                    imp_cost, imp_time, imp_iter, imp_len)
     if retry_overflow and penalty_bits in (0, 16):
         bad = (status == STATUS_PENALTY_OVERFLOW).nonzero().flatten()
         if bad.numel() > 0:
             sub = gls_run(D[bad].contiguous(), None if guides is None else guides[:, bad].contiguous(),
                           init_tour[bad].contiguous(), init_cost[bad].contiguous(), perturbation_moves,
                           first_improvement, max_outer_iters, time_limit_s, watchdog_s, trace_cap, want_trace_time,
-                          want_penalty, penalty_bits=32, retry_overflow=False)
+                          want_penalty, penalty_bits=32, retry_overflow=False, imp_cap=imp_cap)
             for name in ("best_tour", "best_cost", "outer_iters", "trace_cost", "trace_time", "trace_len", "penalty",
-                         "evals", "status"):
+                         "evals", "status", "imp_cost", "imp_time", "imp_iter", "imp_len"):
                 dst, src = getattr(res, name), getattr(sub, name)
                 if dst is not None:
                     dst[bad] = src

@@ -10,6 +10,7 @@ The 10 s budget of the reference starts before the forward pass (test.py:64), so
 persistent workgroup each); larger batches are processed in chunks, each with its own budget.
 """
 import time
+import warnings
 from dataclasses import dataclass, field
 
 import torch
@@ -58,6 +59,13 @@ class SolveResult:
     timing: dict = field(default_factory=dict)
     trace_cost: torch.Tensor = None
     trace_time: torch.Tensor = None
+    # bounded improvement record (the returned best whenever it improved, ops.GlsResult) and the host clock
+    imp_cost: torch.Tensor = None
+    imp_time: torch.Tensor = None
+    imp_iter: torch.Tensor = None
+    imp_len: torch.Tensor = None
+    start_time: torch.Tensor = None    # [B] fp64 host time.time() at which the instance's budget started (test.py:64)
+    launch_time: torch.Tensor = None   # [B] fp64 host time.time() just before its search kernel was launched
 
 
 def predict_regret(model, D, scalers):
@@ -70,7 +78,7 @@ def predict_regret(model, D, scalers):
 
 def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit=10.0, perturbation_moves=20,
                 first_improvement=False, max_outer_iters=-1, trace_cap=0, want_trace_time=False, chunk=None,
-                keep_regret=False, budget="per_instance"):
+                keep_regret=False, budget="per_instance", imp_cap=0):
     """D [B,n,n] fp64 CUDA tensor (symmetric).  Returns SolveResult with per-instance tensors.
 
     budget="per_instance" (default, the reference's meaning of --time_limit, test.py:64,92): every instance is searched
@@ -88,6 +96,13 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
     for g in guides:
         if g not in ("regret_pred", "weight"):
             raise ValueError(f"unknown guide {g!r}")
+    if B == 0:                            # an empty shard (more ranks than instances): nothing to launch
+        e64 = torch.zeros((0,), dtype=torch.float64, device=D.device)
+        ei64, ei32 = e64.long(), e64.int()
+        return SolveResult(best_tour=torch.zeros((0, n + 1), dtype=torch.int32, device=D.device), best_cost=e64,
+                           init_cost=e64, outer_iters=ei64, evals=ei64, moves=ei32, status=ei32,
+                           timing={"forward_s": 0.0, "init_s": 0.0, "search_s": 0.0, "chunks": 0},
+                           start_time=e64.cpu(), launch_time=e64.cpu())
     cap = ops.gls_resident_capacity(n)
     if chunk is None:
         chunk = cap if cap > 0 else 64
@@ -106,7 +121,9 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
             R = predict_regret(model, Dc, scalers)
             torch.cuda.synchronize()
         t1 = time.time()
-        init = ops.nearest_neighbor(R if guides[0] == "regret_pred" else Dc)   # test.py:85-88
+        # test.py:70-88: the start tour is greedy on 'regret_pred' whenever that guide is used AT ALL (not only when it
+        # comes first), otherwise on 'weight'
+        init = ops.nearest_neighbor(R if need_model else Dc)
         init_cost = ops.tour_cost(init, Dc)                                # test.py:90
         gt = torch.stack([R if g == "regret_pred" else Dc for g in guides]).contiguous()
         torch.cuda.synchronize()
@@ -114,14 +131,19 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         remaining = max(round_limit - (t2 - t0), 0.0)
         r = ops.gls_run(Dc, gt, init, init_cost, perturbation_moves=perturbation_moves,
                         first_improvement=first_improvement, max_outer_iters=max_outer_iters,
-                        time_limit_s=remaining, trace_cap=trace_cap, want_trace_time=want_trace_time)
+                        time_limit_s=remaining, trace_cap=trace_cap, want_trace_time=want_trace_time, imp_cap=imp_cap)
         torch.cuda.synchronize()
         t3 = time.time()
+        aborted = int((r.status == ops.STATUS_WATCHDOG).sum())
+        if aborted:
+            warnings.warn(f"solve_batch: the device watchdog stopped {aborted} search(es) early (best-so-far returned)",
+                          RuntimeWarning, stacklevel=2)
         timing["forward_s"] += t1 - t0
         timing["init_s"] += t2 - t1
         timing["search_s"] += t3 - t2
         timing["chunks"] += 1
-        outs.append((r, init_cost, R if keep_regret else None))
+        outs.append((r, init_cost, R if keep_regret else None,
+                     torch.full((Dc.shape[0],), t0, dtype=torch.float64), torch.full((Dc.shape[0],), t2, dtype=torch.float64)))
     cat = lambda xs: torch.cat(xs) if len(xs) > 1 else xs[0]  # noqa: E731
     return SolveResult(
         best_tour=cat([o[0].best_tour for o in outs]), best_cost=cat([o[0].best_cost for o in outs]),
@@ -130,7 +152,12 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         status=cat([o[0].status for o in outs]),
         regret_pred=cat([o[2] for o in outs]) if keep_regret and need_model else None, timing=timing,
         trace_cost=cat([o[0].trace_cost for o in outs]) if trace_cap > 0 else None,
-        trace_time=cat([o[0].trace_time for o in outs]) if (trace_cap > 0 and want_trace_time) else None)
+        trace_time=cat([o[0].trace_time for o in outs]) if (trace_cap > 0 and want_trace_time) else None,
+        imp_cost=cat([o[0].imp_cost for o in outs]) if imp_cap > 0 else None,
+        imp_time=cat([o[0].imp_time for o in outs]) if imp_cap > 0 else None,
+        imp_iter=cat([o[0].imp_iter for o in outs]) if imp_cap > 0 else None,
+        imp_len=cat([o[0].imp_len for o in outs]) if imp_cap > 0 else None,
+        start_time=cat([o[3] for o in outs]), launch_time=cat([o[4] for o in outs]))
 
 
 def synthetic_model(seed=1234, device="cuda"):

@@ -106,6 +106,17 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  *                trace_len [B] = number of accepted moves (may exceed trace_cap),
  *                penalty_out [B,n,n] int32 final penalties (optional),
  *                evals_out [B] int64 number of delta evaluations (optional), status [B] (optional)
+ *   improvement trace (optional, any of the arrays may be NULL; imp_len == NULL disables it): one entry whenever the
+ *                returned best improves -- after the initial descent (algorithms.py:143) and after an outer
+ *                iteration whose descent ends below the best so far (algorithms.py:190-191):
+ *                imp_cost [B,imp_cap] the new best cost, imp_time [B,imp_cap] seconds since workgroup start,
+ *                imp_iter [B,imp_cap] int64 number of completed outer iterations (0 = initial descent),
+ *                followed by ONE terminal entry (best_cost[b], time at the end of the search, outer_iters[b]);
+ *                imp_len [B] = improvements + 1 (may exceed imp_cap: the terminal entry then takes the last slot, so
+ *                with imp_cap >= 1 entry min(imp_len, imp_cap) - 1 is always the terminal one).
+ *                A 10 s TSP100 search accepts ~2e6 moves but improves its best a few dozen times: this is the
+ *                search-progress record (test.py:97-117, `best_cost` = cummin) that stays bounded at any run length;
+ *                the per-move trace is exact while trace_len[b] <= trace_cap and TRUNCATED beyond (callers must check).
  * If trace_cap == 0 the per-move tour_cost recomputation (algorithms.py:176) is deferred to the
  * end of each perturbation phase -- the values that drive decisions are unchanged. */
 int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, int n,
@@ -114,7 +125,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
                    int64_t max_outer_iters, double time_limit_s, double watchdog_s,
                    int32_t *best_tour, double *best_cost, int64_t *outer_iters,
                    double *trace_cost, float *trace_time, int trace_cap, int32_t *trace_len,
-                   int32_t *penalty_out, int64_t *evals_out, int32_t *status, void *stream);
+                   int32_t *penalty_out, int64_t *evals_out, int32_t *status,
+                   double *imp_cost, float *imp_time, int64_t *imp_iter, int imp_cap, int32_t *imp_len, void *stream);
 
 /* ---- K1/K2: edge-regret GNN forward ------------------------------------------------------------
  * EdgePropertyPredictionModel.forward (models.py:44-70) on the line graph of K_n (datasets.py:56-60),

@@ -250,6 +250,7 @@ def main():
                             model_seed=1234, sd_seed=99, sd_checksum=np.float64(checksum),
                             n_params=sum(p.numel() for p in ref_model.parameters()))
     gen_train(ref)
+    gen_progress(ref)
     print("golden vectors written to", GOLD)
 
 
@@ -293,8 +294,71 @@ def gen_train(ref):
         np.savez_compressed(os.path.join(GOLD, f"train_n{n}.npz"), **out)
 
 
+PROGRESS_CASES = [
+    # n, K, guides, perturbation_moves -- start tour as scripts/test.py:70-88 builds it: greedy on 'regret_pred' whenever
+    # that guide is used at all (also when it is not the first one), else on 'weight'
+    (20, 60, ["weight", "regret_pred"], 20),
+    (50, 40, ["weight"], 20),
+    (50, 25, ["weight", "regret_pred"], 10),
+    (100, 30, ["regret_pred"], 20),
+]
+
+
+def gen_progress(ref):
+    """(10) the trajectory of the RETURNED best (algorithms.py:143,190-191) under the fake clock: the cost every
+    local_search call of the reference returns is captured, and the improvement record = its strict running minima
+    (call 0 = the initial descent -> iteration 0, call k -> k completed outer iterations) plus a terminal entry
+    -> tests/golden/gls_imp_c*.npz (pins the oracle's / the device's improvement trace)."""
+    rng = np.random.default_rng(20261002)
+    alg = ref.algorithms
+    for ci, (n, K, guides, pm) in enumerate(PROGRESS_CASES):
+        G = make_graph(rng.random((n, 2)))
+        for e in G.edges:
+            G.edges[e]["regret_pred"] = np.maximum(np.float32(rng.normal(0.05, 0.1)).item(), 0)
+        D = np.asarray(nx.attr_matrix(G, "weight")[0])
+        W = {g: np.asarray(nx.attr_matrix(G, g)[0]) for g in guides}
+        init_guide = "regret_pred" if "regret_pred" in guides else "weight"              # test.py:70,85,88
+        init_tour = alg.nearest_neighbor(G, 0, weight=init_guide)
+        init_cost = ref.tour_cost(G, init_tour)
+        ls_costs = []
+        real_ls = alg.local_search
+
+        def recording_ls(*a, **kw):
+            r = real_ls(*a, **kw)
+            ls_costs.append(r[1])
+            return r
+
+        alg.local_search = recording_ls
+        try:
+            best_tour, best_cost, trace, pen = run_ref_gls(ref, G, list(init_tour), init_cost, K, guides, pm, False)
+        finally:
+            alg.local_search = real_ls
+        assert len(ls_costs) == K + 1
+        imp_cost, imp_iter, best = [], [], None
+        for k, c in enumerate(ls_costs):
+            if best is None or c < best:
+                best = c
+                imp_cost.append(c)
+                imp_iter.append(k)
+        assert best == best_cost
+        imp_cost.append(best_cost)
+        imp_iter.append(K)
+        np.savez_compressed(
+            os.path.join(GOLD, f"gls_imp_c{ci}_n{n}_K{K}.npz"),
+            D=D, guides=np.stack([W[g] for g in guides]), guide_names=np.array(guides), init_guide=np.array(init_guide),
+            nn_guide=np.asarray(nx.attr_matrix(G, init_guide)[0]),
+            init_tour=np.array(init_tour, dtype=np.int32), init_cost=np.float64(init_cost),
+            K=K, perturbation_moves=pm, first_improvement=0,
+            best_tour=np.array(best_tour, dtype=np.int32), best_cost=np.float64(best_cost),
+            trace=np.array(trace, dtype=np.float64), penalty=pen.astype(np.int32),
+            imp_cost=np.array(imp_cost, dtype=np.float64), imp_iter=np.array(imp_iter, dtype=np.int64))
+        print(f"gls_imp_c{ci}: n={n} K={K} moves={len(trace)} improvements={len(imp_cost) - 1}")
+
+
 if __name__ == "__main__":
-    if "--only-train" in sys.argv:          # adds the training fixtures without rewriting the others
+    if "--only-progress" in sys.argv:       # adds the improvement-record fixtures without rewriting the others
+        gen_progress(ref_import.import_reference())
+    elif "--only-train" in sys.argv:          # adds the training fixtures without rewriting the others
         gen_train(ref_import.import_reference(with_models=True))
     else:
         main()

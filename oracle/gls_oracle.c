@@ -232,6 +232,9 @@ static double now_s(void) {
  *   max_outer_iters >= 0 : run exactly that many outer iterations (deterministic / parity mode)
  *   max_outer_iters <  0 : run until time_limit_s of wall clock has elapsed (reference mode, :146)
  *   penalty_out (optional) n*n int32 final penalties
+ *   imp_cost/imp_iter/imp_len (optional): the returned best and the number of completed outer iterations at every
+ *            point where `best_cost` is (re)assigned (:143 -> iteration 0, :190-191 -> iter_i + 1), then one
+ *            terminal entry (best_cost, outer iterations completed); *imp_len counts all of them
  * Returns best_cost.
  */
 double gls_oracle_guided_local_search(const double *D, const double *guides, int n_guides, int n,
@@ -240,7 +243,8 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
                                       int64_t max_outer_iters, double time_limit_s,
                                       double *trace_cost, int trace_cap, int *trace_len,
                                       int32_t *penalty_out, int64_t *outer_iters_out,
-                                      int64_t *evals_out) {
+                                      int64_t *evals_out,
+                                      double *imp_cost, int64_t *imp_iter, int imp_cap, int *imp_len) {
     double t0 = now_s();
     size_t nn = (size_t)n * (size_t)n;
     double k = 0.1 * init_cost / (double)n;                      /* :137 (left to right) */
@@ -256,6 +260,9 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     local_search_impl(cur, &cur_cost, D, n, first_improvement, &tr, &evals);   /* :142 */
     double best_cost = cur_cost;                                  /* :143 */
     memcpy(tour, cur, (size_t)(n + 1) * sizeof(int32_t));
+    int n_imp = 0;
+    if (imp_cost && n_imp < imp_cap) { imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = 0; }
+    n_imp++;
 
     int64_t iter_i = 0;
     for (;;) {
@@ -304,6 +311,8 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
         if (cur_cost < best_cost) {                               /* :190-191 */
             best_cost = cur_cost;
             memcpy(tour, cur, (size_t)(n + 1) * sizeof(int32_t));
+            if (imp_cost && n_imp < imp_cap) { imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = iter_i + 1; }
+            n_imp++;
         }
         iter_i++;
     }
@@ -311,6 +320,12 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     if (trace_len) *trace_len = tr.len;
     if (outer_iters_out) *outer_iters_out = iter_i;
     if (evals_out) *evals_out = evals;
+    if (imp_cost && imp_cap > 0) {                                /* terminal entry: returned best, completed iterations */
+        int q = n_imp < imp_cap ? n_imp : imp_cap - 1;
+        imp_cost[q] = best_cost; if (imp_iter) imp_iter[q] = iter_i;
+    }
+    n_imp++;
+    if (imp_len) *imp_len = n_imp;
     free(pen); free(Dg); free(cur);
     return best_cost;
 }

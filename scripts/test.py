@@ -3,8 +3,18 @@
 """Evaluation entry point with the command line and the output of the reference's scripts/test.py
 (test.py:20-123): `test.py data_path model_path run_dir guides... [--time_limit 10.] [--perturbation_moves 20]
 [--use_gpu]`, per-instance semantics unchanged (the budget starts before the forward pass, nearest-neighbour start
-on the first guide, guided_local_search, gap vs the optimum stored in the instances) and the same DataFrame pickle
-(columns instance, time, opt_cost, cost, best_cost, gap, dt) in `run_dir/<timestamp>_<uuid>.pkl`.
+on 'regret_pred' whenever that guide is used and on 'weight' otherwise (test.py:70-88), guided_local_search, gap vs the
+optimum stored in the instances) and the same DataFrame pickle (columns instance, time, opt_cost, cost, best_cost, gap,
+dt) in `run_dir/<timestamp>_<uuid>.pkl`.
+
+Search progress (test.py:97-117).  The reference appends one row per accepted move; a 10 s TSP100 search on the GPU
+accepts ~2e6 moves per instance, i.e. ~20 GB of rows for a 1024-instance batch.  The default record here is therefore
+the bounded one the device keeps at any run length: one row whenever the returned best improves plus a terminal row
+(end of the search, returned best cost) -- exactly the rows that determine the `best_cost` (cummin), `gap` and `dt`
+columns; `best_cost` of an instance's last row always equals the returned cost.  `--full_trace CAP` additionally keeps
+the first CAP per-move rows of every instance (the reference's record verbatim while moves <= CAP); if an instance
+accepts more moves than that, its rows continue with the improvement record and a warning is printed -- never a
+silently truncated DataFrame.
 
 What differs is the execution: instead of one instance at a time (test.py:59) whole batches are searched on the GPU,
 every instance of a batch getting the full --time_limit concurrently (gnngls_amd.pipeline.solve_batch).  `--use_gpu`
@@ -33,7 +43,7 @@ import gnngls_amd  # noqa: E402
 from gnngls_amd import datasets, models, ops, parallel, pipeline  # noqa: E402
 from gnngls_amd.algorithms import _attr_matrix  # noqa: E402
 
-TRACE_CAP = 1 << 14
+IMP_CAP = 1024
 
 
 def parse_args():
@@ -49,6 +59,8 @@ def parse_args():
     parser.add_argument('--per_batch_budget', type=int, default=0, metavar='R',
                         help='search R x batch_size instances within ONE --time_limit (each gets time_limit / R) '
                              'instead of giving every instance the full budget')
+    parser.add_argument('--full_trace', type=int, default=0, metavar='CAP',
+                        help='also record the first CAP accepted moves of every instance (the reference records all)')
     return parser.parse_args()
 
 
@@ -74,24 +86,47 @@ def load_model(args, params, test_set):
     return model.to(device).eval(), pipeline.Scalers.from_sklearn(test_set.scalers)
 
 
+def progress_rows(res, k, full_trace):
+    """(dt since the instance's search kernel started, cost) rows of instance k, see the module docstring."""
+    rows, t_cut = [], -1.0
+    if full_trace > 0:
+        moves = int(res.moves[k])
+        kept = min(moves, full_trace)
+        rows = list(zip(res.trace_time[k, :kept].tolist(), res.trace_cost[k, :kept].tolist()))
+        if moves <= full_trace:
+            return rows, False
+        t_cut = rows[-1][0] if rows else -1.0
+    m = min(int(res.imp_len[k]), res.imp_cost.shape[1])
+    rows += [(dt, c) for dt, c in zip(res.imp_time[k, :m].tolist(), res.imp_cost[k, :m].tolist()) if dt > t_cut]
+    return rows, full_trace > 0
+
+
 def solve_block(names, test_set, model, scalers, args, chunk, budget='per_instance'):
     """One batch of instances -> (search-progress records, gaps), the body of the loop at test.py:59-109."""
     graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
     optima = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
     D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
-    started = time.time()                                                     # the budget starts here (test.py:64)
-    records = [{'instance': name, 'time': started, 'opt_cost': opt} for name, opt in zip(names, optima)]
     res = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
-                               perturbation_moves=args.perturbation_moves, trace_cap=TRACE_CAP, want_trace_time=True,
-                               chunk=chunk, budget=budget)
-    moves = res.moves.cpu().numpy()
-    costs, stamps = res.trace_cost.cpu().numpy(), res.trace_time.cpu().numpy()
-    gaps = []
+                               perturbation_moves=args.perturbation_moves, trace_cap=args.full_trace,
+                               want_trace_time=args.full_trace > 0, chunk=chunk, budget=budget, imp_cap=IMP_CAP)
+    res.imp_cost, res.imp_time, res.imp_len = res.imp_cost.cpu(), res.imp_time.cpu(), res.imp_len.cpu()
+    res.moves = res.moves.cpu()
+    if args.full_trace > 0:
+        res.trace_cost, res.trace_time = res.trace_cost.cpu(), res.trace_time.cpu()
+    best, started, launched = res.best_cost.cpu().numpy(), res.start_time.numpy(), res.launch_time.numpy()
+    records, gaps, cut = [], [], 0
     for k, (name, opt) in enumerate(zip(names, optima)):
-        kept = min(int(moves[k]), costs.shape[1])
-        records += [{'instance': name, 'opt_cost': opt, 'time': started + float(dt), 'cost': float(c)}
-                    for c, dt in zip(costs[k, :kept], stamps[k, :kept])]
-        gaps.append((res.best_cost[k].item() / opt - 1) * 100)                # test.py:104
+        # the budget of an instance starts before its forward pass (test.py:64); device times count from the launch
+        # of its search kernel
+        records.append({'instance': name, 'time': float(started[k]), 'opt_cost': opt})
+        rows, truncated = progress_rows(res, k, args.full_trace)
+        cut += truncated
+        records += [{'instance': name, 'opt_cost': opt, 'time': float(launched[k]) + dt, 'cost': c} for dt, c in rows]
+        assert rows and rows[-1][1] == best[k], 'the search-progress record must end on the returned cost'
+        gaps.append((best[k] / opt - 1) * 100)                                # test.py:104
+    if cut:
+        print(f'warning: {cut} instance(s) accepted more than --full_trace {args.full_trace} moves; their rows '
+              f'continue with new-best events only', file=sys.stderr)
     return records, gaps
 
 

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_queries(lib):
-    assert lib.gnngls_abi_version() == 1
+    assert lib.gnngls_abi_version() == 2
     assert lib.gnngls_gls_resident_capacity(2) == 0
     caps = [lib.gnngls_gls_resident_capacity(n) for n in (20, 50, 100, 150)]
     assert all(c > 0 for c in caps) and caps == sorted(caps, reverse=True)
@@ -69,7 +69,7 @@ def test_bad_arguments_are_rejected(lib):
     assert b"tour_cost" in lib.gnngls_last_error()
     with pytest.raises(_lib.GnnglsHipError):
         _lib.check(lib.gnngls_gls_run(None, None, 0, 1, 5, None, None, 20, 0, 0, 0, 0.0, 1.0, None, None, None, None, None,
-                                      0, None, None, None, None, None), "gls_run")
+                                      0, None, None, None, None, None, None, None, 0, None, None), "gls_run")
 
 
 def test_no_cpu_fallback_without_gpu():

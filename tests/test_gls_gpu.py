@@ -148,6 +148,45 @@ def test_gls_batch_vs_oracle(ops, n, B, K):
         assert int(r.evals[b]) == o["evals"]
 
 
+@pytest.mark.parametrize("n,B,K", [(131, 3, 2), (160, 3, 2), (200, 3, 2)])
+@pytest.mark.parametrize("fi", [False, True])
+def test_gls_compact_store_one_workgroup_per_cu_vs_oracle(ops, n, B, K, fi):
+    """BASELINE configs[4] regime (TSP200; n = 131..200): the compact store with ONE workgroup per CU (up to 159 KB of
+    LDS for the distance triangle), no row-on-the-lane descent (n - 1 > 128), four register passes of cached
+    utilities.  Two guides, both improvement modes: every accepted move, the best tour / cost, the final penalties,
+    the evaluation count and the improvement record equal the CPU oracle's bit for bit."""
+    from oracle import gls_oracle as go
+    cfg = ops.gls_describe_config(n, B)
+    assert cfg["store"] == "compact" and cfg["per_cu"] == 1 and cfg["lds_bytes"] > 80 * 1024
+    rng = np.random.default_rng(4000 + n)
+    D, _ = random_instances(rng, B, n)
+    guide = np.maximum(rng.normal(0.05, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)
+    guide = np.triu(guide, 1)
+    guide = guide + guide.transpose(0, 2, 1)
+    guides = np.stack([guide, D])
+    d, gd = dev(D, torch.float64), dev(guides, torch.float64)
+    init = ops.nearest_neighbor(gd[0])
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
+                    trace_cap=1 << 14, want_penalty=True, imp_cap=32)
+    plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K)   # no-trace kernel
+    init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
+    for b in range(B):
+        assert init_h[b].tolist() == go.nearest_neighbor(guide[b])
+        o = go.guided_local_search(D[b], guides[:, b], init_h[b], cost_h[b], perturbation_moves=20, first_improvement=fi,
+                                   max_outer_iters=K)
+        L = o["trace_len"]
+        assert int(r.status[b]) == 0 and int(r.trace_len[b]) == L and int(plain.trace_len[b]) == L
+        assert_bits(r.trace_cost[b, :L].cpu().numpy(), o["trace"])
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"] == plain.best_tour[b].cpu().tolist()
+        assert_bits(r.best_cost[b].item(), o["best_cost"])
+        assert_bits(plain.best_cost[b].item(), o["best_cost"])
+        assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"])
+        assert int(r.evals[b]) == o["evals"] == int(plain.evals[b])
+        assert int(r.imp_len[b]) == o["imp_len"]
+        assert_bits(r.imp_cost[b, :o["imp_len"]].cpu().numpy(), o["imp_cost"])
+
+
 def test_gls_global_store_fallback(ops):
     """n too large for the LDS triangles -> global-memory store path; same results as the oracle."""
     from oracle import gls_oracle as go
@@ -310,6 +349,42 @@ def test_full_size_batch_properties(ops):
     assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
     assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all()
     assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("n,B,limit,min_iters", [(50, 128, 1.0, 200), (200, 256, 2.0, 20)])
+def test_config_size_batch_properties(ops, n, B, limit, min_iters):
+    """BASELINE configs[1] (TSP50 x 128) and configs[4] (TSP200 x 256 per GPU) at full size in wall-clock mode: one
+    round (everything resident), valid tours whose recomputed cost equals the reported cost, never worse than plain
+    local search, no watchdog aborts; sampled instances re-run on the CPU oracle for exactly the iterations they
+    completed give the same tour and cost bit for bit."""
+    from oracle import gls_oracle as go
+    assert ops.gls_resident_capacity(n) >= B
+    D, _ = random_instances(np.random.default_rng(50 + n), B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    g = d[None].contiguous()
+    ls = ops.gls_run(d, None, init, cost, max_outer_iters=0)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    r = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=limit)
+    t1.record(); torch.cuda.synchronize()
+    assert t0.elapsed_time(t1) < limit * 1000.0 + 1500.0
+    assert (r.status == 0).all() and (r.outer_iters >= min_iters).all(), r.outer_iters.min()
+    assert (r.best_cost <= ls.best_cost).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
+    assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all()
+    assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
+    iters, init_h, cost_h = r.outer_iters.cpu().numpy(), init.cpu().numpy(), cost.cpu().numpy()
+    order = np.argsort(iters)
+    for b in [int(order[0]), int(order[len(order) // 2])]:           # cheapest and median instance (oracle time)
+        if float(iters[b]) * n * n > 4e8:                             # keep the oracle re-run to seconds
+            continue
+        o = go.guided_local_search(D[b], D[b][None], init_h[b], cost_h[b], perturbation_moves=20,
+                                   max_outer_iters=int(iters[b]), trace_cap=1, want_penalty=False)
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"], (b, int(iters[b]))
+        assert_bits(r.best_cost[b].item(), o["best_cost"])
 
 
 @pytest.mark.parametrize("n,B,limit", [(30, 12, 0.2), (100, 8, 0.3)])

@@ -74,6 +74,30 @@ def test_guided_local_search(path):
     assert np.array_equal(r["penalty"], g["penalty"])
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "gls_imp_c*.npz"))), ids=os.path.basename)
+def test_guided_local_search_improvement_record(path):
+    """The trajectory of the RETURNED best (algorithms.py:143,190-191), captured from the reference's own local_search
+    return values, and the scripts/test.py rule for the start tour (greedy on 'regret_pred' whenever it is among the
+    guides, test.py:70-88 -- also when 'weight' comes first)."""
+    g = np.load(path)
+    assert go.nearest_neighbor(g["nn_guide"]) == g["init_tour"].tolist()
+    assert_bits(go.tour_cost(g["init_tour"], g["D"]), g["init_cost"])
+    r = go.guided_local_search(g["D"], g["guides"], g["init_tour"], float(g["init_cost"]),
+                               perturbation_moves=int(g["perturbation_moves"]), max_outer_iters=int(g["K"]))
+    assert_bits(r["trace"], g["trace"])
+    assert r["best_tour"] == g["best_tour"].tolist() and np.array_equal(r["penalty"], g["penalty"])
+    assert r["imp_len"] == len(g["imp_cost"])
+    assert_bits(r["imp_cost"], g["imp_cost"])
+    assert np.array_equal(r["imp_iter"], g["imp_iter"])
+    assert_bits(r["imp_cost"][-1], r["best_cost"])
+    # a buffer that is too small still ends on the terminal entry
+    small = go.guided_local_search(g["D"], g["guides"], g["init_tour"], float(g["init_cost"]),
+                                   perturbation_moves=int(g["perturbation_moves"]), max_outer_iters=int(g["K"]), imp_cap=2)
+    assert small["imp_len"] == len(g["imp_cost"]) and len(small["imp_cost"]) == 2
+    assert_bits(small["imp_cost"], [g["imp_cost"][0], g["best_cost"]])
+    assert small["imp_iter"].tolist() == [0, int(g["K"])]
+
+
 def test_misc():
     g = np.load(os.path.join(GOLD, "misc.npz"))
     assert go.nearest_neighbor(g["nn_W_weight"]) == g["nn_tour_weight"].tolist()

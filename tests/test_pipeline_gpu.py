@@ -44,6 +44,62 @@ def test_solve_batch_matches_oracle_chain(model):
         assert fbits(r.best_cost[b].item()) == fbits(o["best_cost"])
 
 
+def test_solve_batch_start_tour_rule_with_weight_first(model):
+    """guides = ['weight', 'regret_pred'] (the alternating-guide case algorithms.py:147 supports): the reference starts
+    from nearest_neighbor on 'regret_pred' whenever that guide is used at all (test.py:70-88), not on the first guide.
+    The oracle is driven exactly as test.py drives the reference."""
+    from gnngls_amd import pipeline
+    from gnngls_amd.synthetic import random_instances
+    from oracle import gls_oracle as go
+    n, B, K = 24, 5, 6
+    D_host, _ = random_instances(np.random.default_rng(17), B, n)
+    D = torch.from_numpy(D_host).cuda()
+    sc = pipeline.Scalers.fit_weights(D)
+    r = pipeline.solve_batch(D, model, sc, guides=("weight", "regret_pred"), max_outer_iters=K, perturbation_moves=20,
+                             trace_cap=4096, keep_regret=True)
+    R = r.regret_pred.cpu().numpy()
+    differs = 0
+    for b in range(B):
+        init = go.nearest_neighbor(R[b])                                     # test.py:85
+        differs += init != go.nearest_neighbor(D_host[b])
+        cost = go.tour_cost(init, D_host[b])                                 # test.py:90
+        assert fbits(r.init_cost[b].item()) == fbits(cost)
+        o = go.guided_local_search(D_host[b], np.stack([D_host[b], R[b]]), init, cost, perturbation_moves=20,
+                                   max_outer_iters=K)
+        L = o["trace_len"]
+        assert int(r.moves[b]) == L
+        assert np.array_equal(fbits(r.trace_cost[b, :L].cpu().numpy()), fbits(o["trace"]))
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+    assert differs > 0                                                       # the rule is observable on this batch
+
+
+@pytest.mark.parametrize("n,B,limit", [(50, 128, 1.5), (200, 256, 4.0)])
+def test_solve_batch_config_sizes_end_to_end(model, n, B, limit):
+    """BASELINE configs[1] (TSP50 x 128: GNN forward + GLS) and configs[4] (TSP200 x 256 per GPU) through the whole
+    pipeline in ONE round: forward, regret guide, start tours, search within the remaining budget; results are valid
+    tours with consistent costs, never worse than the start, no aborts, the budget is respected."""
+    import time
+    from gnngls_amd import ops, pipeline
+    from gnngls_amd.synthetic import random_instances
+    D = torch.from_numpy(random_instances(np.random.default_rng(n), B, n)[0]).cuda()
+    sc = pipeline.Scalers.fit_weights(D)
+    pipeline.solve_batch(D[:2].contiguous(), model, sc, time_limit=0.05)     # warm-up (module load, workspace)
+    t0 = time.time()
+    r = pipeline.solve_batch(D, model, sc, guides=("regret_pred",), time_limit=limit, imp_cap=64)
+    wall = time.time() - t0
+    assert r.timing["chunks"] == 1 and wall < limit + 1.5
+    assert r.timing["forward_s"] < limit / 2
+    assert (r.status == 0).all() and (r.outer_iters > 5).all()
+    assert (r.best_cost <= r.init_cost).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (bt[:, 0] == 0).all() and (bt[:, -1] == 0).all()
+    assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all()
+    assert torch.allclose(ops.tour_cost(r.best_tour, D), r.best_cost, rtol=1e-12, atol=0)
+    L = r.imp_len.cpu().numpy()
+    last = r.imp_cost.cpu().numpy()[np.arange(B), np.minimum(L, 64) - 1]
+    assert np.array_equal(fbits(last), fbits(r.best_cost.cpu().numpy()))
+
+
 def test_solve_batch_chunking_and_weight_guide(model):
     """A batch larger than the chunk size is processed in chunks with identical results; guides=['weight'] needs no model."""
     from gnngls_amd import pipeline
