@@ -87,6 +87,10 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
         if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }
         if (batch > 0 && (long)per_cu * cus >= batch) { pick = GlsConfig{store, bits, threads, lds, per_cu}; done = true; }
     };
+    if (requested_bits == -2) {               // forced compact store (falls through to the global store if it cannot fit)
+        if (n <= 255) consider(gnngls::GLS_STORE_COMPACT, 32);
+        return pick;
+    }
     if (requested_bits < 0) return pick;      // forced global-memory store (exact index order, asymmetric D allowed)
     if (requested_bits == 0 || requested_bits == 32) consider(gnngls::GLS_STORE_TRI, 32);
     // 16-bit LDS counters only on request: they overflow within a 10 s run when an uninformative guide
@@ -110,9 +114,11 @@ int gnngls_gls_resident_capacity(int n) {
 }
 
 int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu) {
-    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1))
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
         return fail(GNNGLS_ERR_ARG, "gls_describe_config: bad argument");
     const GlsConfig c = gls_config(n, penalty_bits, B);
+    if (c.lds > kLdsPerCU)
+        return fail(GNNGLS_ERR_UNSUPPORTED, "gls_describe_config: n=%d needs %zu B of LDS for tours and edge lengths (> 160 KiB)", n, c.lds);
     if (store) *store = c.store * 100 + (c.store == gnngls::GLS_STORE_TRI ? c.penalty_bits : 0);
     if (threads) *threads = c.threads;
     if (lds_bytes) *lds_bytes = (int)c.lds;
@@ -177,8 +183,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (max_outer_iters != 0 && (!guides || n_guides < 1))
         return fail(GNNGLS_ERR_ARG, "gls_run: guides required when outer iterations are requested");
     if (!(watchdog_s > 0.0)) return fail(GNNGLS_ERR_ARG, "gls_run: watchdog_s must be > 0");
-    if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1)
-        return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16, 32 or -1 (global-memory store)");
+    if (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2)
+        return fail(GNNGLS_ERR_ARG, "gls_run: penalty_bits must be 0 (auto), 16, 32, -1 (global-memory store) or -2 (compact store)");
     hipStream_t st = (hipStream_t)stream;
     gnngls::GlsArgs A;
     memset(&A, 0, sizeof(A));
@@ -193,6 +199,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.stamps = g_stamp_buffer;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
     const GlsConfig cfg = gls_config(n, penalty_bits, B);
+    if (cfg.lds > kLdsPerCU)     // even the global-memory store keeps tours and per-position edge lengths in LDS
+        return fail(GNNGLS_ERR_UNSUPPORTED, "gls_run: n=%d needs %zu B of LDS for tours and edge lengths (> 160 KiB)", n, cfg.lds);
     int32_t *ws = nullptr;
     if (cfg.store != gnngls::GLS_STORE_TRI) {
         // penalties in global memory (zeroed workspace): full matrices for the global store, packed
@@ -228,10 +236,12 @@ constexpr long kBytesPerNode = (128 + 128 + 256 + 32 + 128) * 4L;   // h, ft, pa
 extern "C" {
 
 int64_t gnngls_model_packed_floats(int in_dim, int n_layers) {
+    if (in_dim < 0 || n_layers < 0) return 0;
     return 128L * in_dim + 128 + (long)n_layers * kLayerFloats + 128 + 4;
 }
 
 int64_t gnngls_regret_forward_workspace_bytes(int B, int n) {
+    if (B < 1 || n < 2 || n > 65535) return 0;          // 65535 nodes x 2^31 instances still fits an int64
     long N = (long)n * (n - 1) / 2;
     return (int64_t)B * N * kBytesPerNode + 256;
 }
@@ -399,7 +409,7 @@ int train_check(const char *what, const void *feat, const void *params, const vo
 extern "C" {
 
 int64_t gnngls_regret_train_workspace_bytes(int B, int n, int n_layers) {
-    if (B < 1 || n < 2 || n_layers < 0) return 0;
+    if (B < 1 || n < 2 || n > 65535 || n_layers < 0 || n_layers > 4096) return 0;
     const long M = (long)B * ((long)n * (n - 1) / 2);
     return (int64_t)train_layout(0, M, n_layers).bytes + 256;
 }

@@ -13,17 +13,24 @@ def shard_range(total, world, rank):
     return lo, min(lo + per, total)
 
 
-def gather_results(local, dst=0):
-    """local [B_local, C] tensor on every rank -> concatenated [sum B_local, C] on rank `dst`, None
-    elsewhere.  Block sizes may differ between ranks."""
+def shard_sizes(total, world):
+    """Rows every rank contributes: a pure function of (total, world), known everywhere without communication."""
+    return [hi - lo for lo, hi in (shard_range(total, world, r) for r in range(world))]
+
+
+def gather_results(local, sizes=None, dst=0):
+    """local [B_local, C] tensor on every rank -> concatenated [sum B_local, C] on rank `dst`, None elsewhere: ONE
+    collective (`gather`).  `sizes` = rows per rank (shard_sizes(total, world)) when the shards are uneven; None means
+    every rank holds the same number of rows.  No size exchange: the shard layout is a function of (total, world)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    all_sizes = [int(s.item()) for s in all_sizes]
-    mx = max(all_sizes)
+    if sizes is None:
+        sizes = [local.shape[0]] * world
+    sizes = [int(x) for x in sizes]
+    if len(sizes) != world or sizes[rank] != local.shape[0]:
+        raise ValueError(f"rank {rank}: {local.shape[0]} local rows but the shard layout says {sizes}")
+    mx = max(sizes)
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
@@ -31,4 +38,4 @@ def gather_results(local, dst=0):
     dist.gather(pad.contiguous(), bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:s] for b, s in zip(bufs, all_sizes)])
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])

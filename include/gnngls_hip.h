@@ -99,6 +99,7 @@ int gnngls_nearest_neighbor(const double *W, int B, int n, int depot, int32_t *t
  *                overflow stops that instance with GNNGLS_STATUS_PENALTY_OVERFLOW; the caller reruns it with 32.
  *                -1 = force the global-memory store: matrices stay in HBM/L2 and every evaluation keeps the
  *                reference's exact index order, so D may be ASYMMETRIC (the LDS stores keep one triangle).
+ *                -2 = force the compact store (distance triangle in LDS, 32-bit counters in global memory; n <= 255).
  *   watchdog_s   hard abort (status GNNGLS_STATUS_WATCHDOG) if a workgroup runs longer than this
  *   outputs      best_tour [B,n+1], best_cost [B], outer_iters [B] (int64),
  *                trace_cost [B,trace_cap] cost after every accepted move (algorithms.py:127-130,

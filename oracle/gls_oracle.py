@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgls_oracle.so")
+# GLS_ORACLE_SO: an alternative build of the same source (tests/test_sanitizers_cpu.py loads an ASan/UBSan build)
+_SO = os.environ.get("GLS_ORACLE_SO") or os.path.join(_HERE, "libgls_oracle.so")
 _lib = None
 
 _f64p = ctypes.POINTER(ctypes.c_double)

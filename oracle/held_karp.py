@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libheld_karp.so")
+_SO = os.environ.get("HELD_KARP_SO") or os.path.join(_HERE, "libheld_karp.so")   # alternative (sanitizer) build
 _lib = None
 
 
@@ -23,7 +23,8 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if "HELD_KARP_SO" not in os.environ:
+            build()
         L = ctypes.CDLL(_SO)
         L.held_karp.restype = ctypes.c_double
         L.held_karp.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]

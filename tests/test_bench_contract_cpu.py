@@ -1,36 +1,73 @@
-"""CPU check of the bench.py output contract on the committed bench line (profiles/): required keys, types, and the
-roofline / cpu_baseline objects the harness reads."""
+"""CPU check of the bench.py output contract on the newest committed bench line (profiles/): required keys, types, and the
+roofline / cpu_baseline objects the harness reads; plus the host-side pieces of bench.py (instance blocks, best-known file)."""
 import glob
+import importlib.util
 import json
 import os
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def latest_bench():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))
-    assert files, "no committed bench line under profiles/"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]*_bench.json")))
+    assert files, "no committed round-2+ bench line under profiles/"
     return json.load(open(files[-1]))
+
+
+def bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
 
 
 def test_bench_line_has_the_contract_keys():
     j = latest_bench()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "mean_gap_pct", "gap_reference"):
         assert k in j, k
-    assert j["unit"] == "instances/s" and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["unit"] == "instances/s" and j["higher_is_better"] is True and j["scaling"] in ("weak", "strong")
     assert j["vs_baseline"] is None and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
-    assert j["value"] > 0 and abs(j["value"] - j["config"]["instances_per_gpu"] * j["n_gpus"] / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    assert j["value"] > 0 and abs(j["value"] - j["config"]["total_instances"] / (j["ms_per_step"] / 1e3)) < 1e-6 * j["value"]
+    # the gap is measured against a committed artifact that is independent of the timed run
+    assert j["mean_gap_pct"] is not None and "bench_data/" in j["gap_reference"]
+    assert os.path.isfile(os.path.join(ROOT, j["gap_reference"].split(":")[0]))
+    assert j["watchdog_aborts"] == 0
 
 
 def test_roofline_and_cpu_baseline_objects():
     j = latest_bench()
     r = j["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    # the kernel that owns the timed step is the search kernel: LDS-bound by design
+    assert r["kernel"] == "gls_kernel" and r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == 150000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
-    assert r["peak"] in (8000.0, 157.3)
+    assert r["delta_evals_per_s"] > 1e10 and r["launches"] == j["steps"] * j["config"]["rounds_per_rank"][0]
+    for k in j["kernels"].values():
+        assert k["bound"] in ("hbm", "mfma") and k["peak"] in (8000.0, 157.3)
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    g = j["roofline_gls"]
-    assert g["delta_evals_per_s"] > 1e10 and g["launches"] == j["steps"] * -(-j["config"]["instances_per_gpu"] // j["config"]["resident_instances_per_gpu"])
+    assert c["per_core_value"] > 0 and "all" in c["sample"]
+
+
+def test_instance_blocks_and_best_known_file(tmp_path):
+    b = bench_module()
+    from gnngls_amd.synthetic import random_instances
+    D = b.instance_range(7, 6, 1020, 1030)                       # straddles blocks 0 and 1
+    assert D.shape == (10, 6, 6)
+    blk0 = random_instances(np.random.default_rng(7), 1024, 6)[0]
+    blk1 = random_instances(np.random.default_rng(1007), 1024, 6)[0]
+    assert np.array_equal(D[:4], blk0[1020:]) and np.array_equal(D[4:], blk1[:6])
+    assert b.instance_range(7, 6, 5, 5).shape == (0, 6, 6)
+    path = str(tmp_path / "bk.npz")
+    a0 = np.arange(1024, dtype=np.float64)
+    a1 = np.full(1024, np.nan)
+    a1[:100] = 5.0
+    np.savez(path, n=6, seed=7, how=np.array("unit test"), block0=a0, block1=a1)
+    bk, how = b.load_best_known(path, 6, 7, 1000, 1030)
+    assert np.array_equal(bk[:24], a0[1000:]) and (bk[24:] == 5.0).all() and "unit test" in how
+    assert b.load_best_known(path, 6, 7, 1000, 1200)[0] is None         # beyond the covered part of block 1
+    assert b.load_best_known(path, 6, 8, 0, 10)[0] is None              # another seed
+    assert b.load_best_known(str(tmp_path / "none.npz"), 6, 7, 0, 10)[0] is None

@@ -148,16 +148,20 @@ def test_gls_batch_vs_oracle(ops, n, B, K):
         assert int(r.evals[b]) == o["evals"]
 
 
-@pytest.mark.parametrize("n,B,K", [(131, 3, 2), (160, 3, 2), (200, 3, 2)])
+@pytest.mark.parametrize("n,B,K,bits,store,per_cu", [
+    (131, 3, 2, -2, "compact", 2), (131, 3, 2, 0, "lds-tri-i32", 1), (160, 3, 2, -2, "compact", 1),
+    (160, 3, 2, 0, "lds-tri-i32", 1), (200, 3, 2, 0, "compact", 1), (200, 2, 1, -2, "compact", 1)])
 @pytest.mark.parametrize("fi", [False, True])
-def test_gls_compact_store_one_workgroup_per_cu_vs_oracle(ops, n, B, K, fi):
-    """BASELINE configs[4] regime (TSP200; n = 131..200): the compact store with ONE workgroup per CU (up to 159 KB of
-    LDS for the distance triangle), no row-on-the-lane descent (n - 1 > 128), four register passes of cached
-    utilities.  Two guides, both improvement modes: every accepted move, the best tour / cost, the final penalties,
-    the evaluation count and the improvement record equal the CPU oracle's bit for bit."""
+def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi):
+    """BASELINE configs[4] regime (TSP200; n = 131..200): one or two workgroups per CU (up to 159 KB of LDS for the
+    distance triangle), no row-on-the-lane descent (n - 1 > 128), four register passes of cached utilities -- on the
+    store gnngls_gls_run picks by itself and on the compact store (the one TSP200 x 256 runs on).  Two guides, both
+    improvement modes: every accepted move, the best tour / cost, the final penalties, the evaluation count and the
+    improvement record equal the CPU oracle's bit for bit."""
     from oracle import gls_oracle as go
-    cfg = ops.gls_describe_config(n, B)
-    assert cfg["store"] == "compact" and cfg["per_cu"] == 1 and cfg["lds_bytes"] > 80 * 1024
+    cfg = ops.gls_describe_config(n, B, penalty_bits=bits)
+    assert cfg["store"] == store and cfg["per_cu"] == per_cu and cfg["lds_bytes"] > 64 * 1024, cfg
+    assert ops.gls_describe_config(200, 256)["store"] == "compact"
     rng = np.random.default_rng(4000 + n)
     D, _ = random_instances(rng, B, n)
     guide = np.maximum(rng.normal(0.05, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)
@@ -168,8 +172,9 @@ def test_gls_compact_store_one_workgroup_per_cu_vs_oracle(ops, n, B, K, fi):
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
     r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
-                    trace_cap=1 << 14, want_penalty=True, imp_cap=32)
-    plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K)   # no-trace kernel
+                    trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
+    plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
+                        penalty_bits=bits)                                                                  # no-trace kernel
     init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
     for b in range(B):
         assert init_h[b].tolist() == go.nearest_neighbor(guide[b])

@@ -21,7 +21,13 @@ def _worker(rank, world, port, total, q):
     lo, hi = parallel.shard_range(total, world, rank)
     # "results" of this rank's instances: column 0 = global instance id, column 1 = a cost
     local = torch.stack([torch.arange(lo, hi, dtype=torch.float64), torch.arange(lo, hi, dtype=torch.float64) * 0.5 + 1], 1)
-    out = parallel.gather_results(local)
+    calls = []
+    real_gather, real_all_gather = dist.gather, dist.all_gather
+    dist.gather = lambda *a, **k: (calls.append("gather"), real_gather(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real_all_gather(*a, **k))[1]
+    out = parallel.gather_results(local, parallel.shard_sizes(total, world))
+    dist.gather, dist.all_gather = real_gather, real_all_gather
+    assert calls == ["gather"]                     # exactly one collective, no size exchange
     if rank == 0:
         q.put(out.tolist())
     else:
