@@ -6,7 +6,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libgnngls_hip.so")
+# GNNGLS_HIP_SO: another build of the same library (A/B kernel experiments, diagnostic -DGLS_STAMPS builds)
+SO = os.environ.get("GNNGLS_HIP_SO") or os.path.join(HERE, "libgnngls_hip.so")
 
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
@@ -37,6 +38,7 @@ SIGNATURES = {
     "gnngls_unpack_regret": [_vp, _int, _int, _f64, _f64, _vp, _vp],
     "gnngls_debug_set_penalty16_limit": [_int],
     "gnngls_debug_set_stamp_buffer": [_vp],
+    "gnngls_debug_set_gls_threads": [_int],
     "gnngls_profile_enable": [_int],
     "gnngls_profile_collect": [_vp, _vp],
 }

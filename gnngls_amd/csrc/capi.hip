@@ -560,6 +560,13 @@ int gnngls_debug_set_penalty16_limit(int limit) {
     return GNNGLS_OK;
 }
 
+int gnngls_debug_set_gls_threads(int threads) {
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512)
+        return fail(GNNGLS_ERR_ARG, "gls threads override must be 0 (default policy), 64, 128, 256 or 512");
+    gnngls::gls_set_block_threads_override(threads);
+    return GNNGLS_OK;
+}
+
 int gnngls_debug_set_stamp_buffer(void *device_buffer) {
     g_stamp_buffer = (long long *)device_buffer;
     return GNNGLS_OK;

@@ -29,7 +29,7 @@ struct GlsArgs {
     int32_t *status;
     int32_t *pen_ws;           // global store: [B,n,n] int32; compact store: [B,n(n-1)/2] int32; zeroed by the host
     int pen16_limit;           // 65535 (see gnngls_debug_set_penalty16_limit)
-    long long *stamps;         // diagnostic builds (-DGLS_STAMPS) only: [B,8] cycle totals, else unused
+    long long *stamps;         // diagnostic builds (-DGLS_STAMPS) only: [B,16] cycle totals, else unused
     // improvement trace: one entry whenever the returned best improves (algorithms.py:143,190-191)
     double *imp_cost;          // [B,imp_cap] or NULL
     float *imp_time;           // [B,imp_cap] seconds since workgroup start, or NULL
@@ -41,6 +41,7 @@ struct GlsArgs {
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
 size_t gls_lds_bytes(int n, int store, int penalty_bits);
 int gls_block_threads(int n, int store);
+void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
                       hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);

@@ -32,29 +32,49 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gls_kernels.h"
 
 #pragma clang fp contract(off)
 
 namespace gnngls {
 
+#ifndef GLS_FUSED_PERTURB
+#define GLS_FUSED_PERTURB 0          // 0: the scan-after-scan perturbation phase (kept for the global store and for A/B runs)
+#endif
+#ifndef GLS_PARALLEL_PERTURB
+#define GLS_PARALLEL_PERTURB 1       // workgroups of >= 4 wavefronts: the four one-to-all scans of a step on four wavefronts
+#endif
+#ifndef GLS_LEAN_UNROLL
+#define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
+#endif
+#ifndef GLS_COMPACT_THREADS
+#define GLS_COMPACT_THREADS 512      // workgroup size of the compact store for n > 80 (4 workgroups per CU at TSP100)
+#endif
 constexpr int kWave = 64;
 constexpr int kNoKey = INT_MAX;
 constexpr int kGuidePassesMax = 4;   // register-cached guide values cover n <= 256
 
 // Diagnostic build only (-DGLS_STAMPS): per-phase shader-cycle totals of the search kernel, written to
 // a side buffer that nothing else reads.  The shipped library is built without it.
+struct Stamps {
 #ifdef GLS_STAMPS
-#define STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_t = 0
-#define STAMP_BEGIN() st_t = clock64()
-#define STAMP_END(i) do { long long st_n = clock64(); st_acc[i] += st_n - st_t; st_t = st_n; } while (0)
-#define STAMP_COUNT(i) st_acc[i] += 1
+    long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long t0 = 0;
+    __device__ __forceinline__ void begin() { t0 = clock64(); }
+    __device__ __forceinline__ void end(int i) { const long long n = clock64(); acc[i] += n - t0; t0 = n; }
+    __device__ __forceinline__ void count(int i) { acc[i] += 1; }
 #else
-#define STAMP_DECL
-#define STAMP_BEGIN()
-#define STAMP_END(i)
-#define STAMP_COUNT(i)
-#endif   // register-cached guide values cover n <= 256
+    __device__ __forceinline__ void begin() {}
+    __device__ __forceinline__ void end(int) {}
+    __device__ __forceinline__ void count(int) {}
+#endif
+};
+#define STAMP_DECL Stamps st
+#define STAMP_BEGIN() st.begin()
+#define STAMP_END(i) st.end(i)
+#define STAMP_COUNT(i) st.count(i)
 
 __device__ __forceinline__ int make_key(int i, int j) { return (i << 16) | j; }
 
@@ -95,6 +115,12 @@ struct TriStore {
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     int limit;         // largest representable count (65535 for 16-bit counters; lowered only by the test hook)
+    // the caller already holds the current count (register-cached): store old + 1 without reading the counter back
+    __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {     // true = counter overflow
+        if (sizeof(PT) == 2 && old_count >= limit) return true;
+        p[idx(a, b)] = (PT)(old_count + 1);
+        return false;
+    }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {     // true = counter overflow
         const int q = idx(a, b);
         const PT v = p[q];
@@ -118,7 +144,8 @@ struct TriDGlobalP {
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
-    static constexpr int kWavesPerSimd = 8;      // 4 workgroups of 8 waves per CU (64 VGPRs)
+    // 4 workgroups per CU: 8 waves each -> 8 per SIMD (64 VGPRs); 4 waves each -> 4 per SIMD (128 VGPRs)
+    static constexpr int kWavesPerSimd = GLS_COMPACT_THREADS / 64;
     static constexpr int kScanUnroll = 1;        // measured: 2-deep batching costs more in spills than it hides (8.6k vs 10.0k)
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
@@ -132,6 +159,10 @@ struct TriDGlobalP {
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
         p[idx(a, b)] += 1;
+        return false;
+    }
+    __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {   // no read-back: store only
+        p[idx(a, b)] = old_count + 1;
         return false;
     }
 };
@@ -157,6 +188,11 @@ struct GlobalStore {
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
         p[(size_t)a * n + b] += 1;
         p[(size_t)b * n + a] += 1;
+        return false;
+    }
+    __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {
+        p[(size_t)a * n + b] = old_count + 1;
+        p[(size_t)b * n + a] = old_count + 1;
         return false;
     }
 };
@@ -521,6 +557,170 @@ __device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *
     }
 }
 
+// ---- lean "row on the lane" scans (best improvement, symmetric stores, n <= 127) -------------------------------------
+// The descent is bound by vector-instruction issue (8 waves per SIMD, ~2.7 of them ready at any time), not by LDS
+// bandwidth: what counts is the number of VALU instructions per evaluation.  These versions keep the row-on-the-lane
+// mapping (lane l owns tour row i = 1 + 64 rb + l; the wavefront walks the other index uniformly) and strip the inner
+// loop to the arithmetic of the reference plus one triangular index:
+//   * the wave-uniform operands of a step (tour node, its triangular row offset, the tour-edge length) never touch
+//     LDS inside the loop: every lane keeps positions l and l + 64 of the tour / edge-length arrays in registers
+//     (loaded once per scan) and the step broadcasts them with v_readlane into SGPRs;
+//   * relocate is enumerated by target EDGE k = (t[k], t[k+1]) instead of by j: for i < j the reference inserts
+//     between t[j], t[j+1] (k = j), for i > j between t[j-1], t[j] (k = j - 1) (operators.py:91-96), so
+//     delta(i, k) = ((base_i - Ef[k+1]) + D[t[k], b]) + D[b, t[k+1]] has ONE form, no per-lane selects, and
+//     D[b, t[k+1]] of step k is D[t[k+1], b] of step k + 1 (symmetric store: same bits): one random LDS read per step;
+//   * within a lane the keys (i, j) ascend, so "first minimum wins" is a plain strict `delta < best` (no key compare);
+//     np.isclose is only evaluated for a candidate that already beats the lane's best.
+// Same deltas (same operand order), same keys, same arg-min as the scans above.
+struct LaneTour {      // positions lane and lane + 64 of the tour (and of Ef) in registers
+    int t0, t1;
+    double e0, e1;
+};
+template <class TT>
+__device__ __forceinline__ LaneTour load_lane_tour(const TT *t, const double *Ef, int n, int lane) {
+    LaneTour L;
+    const int p1 = lane + kWave <= n ? lane + kWave : n;
+    L.t0 = t[lane <= n ? lane : n]; L.t1 = t[p1];
+    L.e0 = Ef[lane <= n ? lane : n]; L.e1 = Ef[p1];          // Ef[0] is never used
+    return L;
+}
+__device__ __forceinline__ int bcast_int(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+__device__ __forceinline__ double bcast_f64(double v, int src_lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// position p (wave-uniform) -> tour node / edge length, from the lane-resident copies
+#define LT_NODE(L, p) ((p) < kWave ? bcast_int((L).t0, (p)) : bcast_int((L).t1, (p) - kWave))
+#define LT_EDGE(L, p) ((p) < kWave ? bcast_f64((L).e0, (p)) : bcast_f64((L).e1, (p) - kWave))
+
+// split [lo, hi) over `parts` consecutive chunks; chunk `c` -> [*a, *b)
+__device__ __forceinline__ void chunk_range(int lo, int hi, int parts, int c, int &a, int &b) {
+    const int len = hi - lo, per = (len + parts - 1) / parts;
+    a = lo + c * per; b = a + per;
+    if (a > hi) a = hi;
+    if (b > hi) b = hi;
+}
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, const double *Ef, int n,
+                                                       int wave, int nwaves, int lane, double &bd, int &bk) {
+    const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows (1 or 2)
+    const int per_rb = nwaves / RW;                          // waves sharing a row block, each a contiguous k range
+    const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
+    const int part = __builtin_amdgcn_readfirstlane(wave - rb * per_rb);
+    if (per_rb == 0 || rb >= RW) return;                     // (nwaves >= RW always holds for the launch shapes used)
+    const LaneTour L = load_lane_tour(t, Ef, n, lane);
+    const int i = 1 + rb * kWave + lane;
+    const bool row_ok = i <= n - 1;                          // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
+    const int ic = row_ok ? i : 1;
+    const int a = t[ic - 1], b = t[ic], cc = t[ic + 1];
+    double base = -Ef[ic];                                   // -D[a,b]
+    base = base - Ef[ic + 1];                                // -D[b,c]
+    base = base + s.dist(a, cc);                             // +D[a,c]
+    const int b2 = (b * (b - 1)) >> 1;
+    int k0, k1;
+    chunk_range(0, n, per_rb, part, k0, k1);                 // target edges k = 0 .. n-1
+    if (k0 >= k1) return;
+    int d = LT_NODE(L, k0);
+    double vd = s.dist_at(s.idx2(b, b2, d, (d * (d - 1)) >> 1));          // D[t[k0], b]   (garbage, unused, where t[k0] == b)
+    // U steps at a time: all wave-uniform operands, indices and the U random distance reads are issued before the first
+    // dependent add, so the LDS round trips of a group overlap (a step alone is a ~280-cycle dependent chain)
+    auto group = [&](int k, int te, double ee, auto ucount) {
+        constexpr int U = decltype(ucount)::value;
+        double ve[U], de[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = bcast_int(te, k + u + 1);          // v_readlane uses the lane index modulo 64
+            const int e2 = (e * (e - 1)) >> 1;               // wave-uniform: scalar ALU
+            de[u] = bcast_f64(ee, k + u + 1);                // D[t[k], t[k+1]]
+            ve[u] = s.dist_at(s.idx2(b, b2, e, e2));         // D[b, t[k+1]]
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + u;
+            double delta = base - de[u];                     // -D[d,e]          (operators.py:100-102, left to right)
+            delta = delta + vd;                              // +D[d,b]
+            delta = delta + ve[u];                           // +D[b,e]
+            vd = ve[u];
+            // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
+            if (row_ok && (unsigned)(kk - i + 2) > 2u && delta < bd) {
+                if (!close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
+            }
+        }
+    };
+    using U4 = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using U1 = std::integral_constant<int, 1>;
+    const int ksplit = kWave - 1;                            // position k + 1 <= 63  <=>  k < 63
+    const int ka = k1 < ksplit ? k1 : ksplit;                // slot 0: k in [k0, ka)
+    int k = k0;
+    for (; k + GLS_LEAN_UNROLL <= ka; k += GLS_LEAN_UNROLL) group(k, L.t0, L.e0, U4{});
+    for (; k < ka; ++k) group(k, L.t0, L.e0, U1{});
+    k = k0 > ksplit ? k0 : ksplit;                           // slot 1: k in [max(k0, 63), k1)
+    for (; k + GLS_LEAN_UNROLL <= k1; k += GLS_LEAN_UNROLL) group(k, L.t1, L.e1, U4{});
+    for (; k < k1; ++k) group(k, L.t1, L.e1, U1{});
+}
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, const double *Eb, int n,
+                                                      int wave, int nwaves, int lane, double &bd, int &bk) {
+    // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39): rows i = 1..n-3, j = i+2..n-1.  Row block rb can use
+    // j >= 3 + 64 rb: block 0 has ~3x the work of block 1, so the waves are shared out in proportion to the j ranges.
+    const int RW = (n - 3 + kWave - 1) / kWave;              // row blocks with at least one valid row
+    if (RW <= 0) return;
+    const int len0 = n - 3, len1 = RW > 1 ? n - 3 - kWave : 0;   // number of j values block 0 / block 1 walks
+    int w1 = RW > 1 ? (nwaves * len1 + (len0 + len1) / 2) / (len0 + len1) : 0;
+    if (RW > 1 && w1 < 1) w1 = 1;
+    if (w1 > nwaves - 1) w1 = nwaves - 1;
+    const int w0 = nwaves - w1;
+    const int rb = __builtin_amdgcn_readfirstlane(wave < w0 ? 0 : 1);
+    const int part = __builtin_amdgcn_readfirstlane(wave < w0 ? wave : wave - w0);
+    const int parts = rb == 0 ? w0 : w1;
+    const LaneTour L = load_lane_tour(t, Eb, n, lane);
+    const int i = 1 + rb * kWave + lane;
+    const bool row_ok = i <= n - 3;
+    const int ic = row_ok ? i : 1;
+    const int a = t[ic], b = t[ic - 1];
+    const int a2 = (a * (a - 1)) >> 1, b2 = (b * (b - 1)) >> 1;
+    const double eab = Eb[ic];                               // D[a,b]
+    int j0, j1;
+    chunk_range(3 + rb * kWave, n, parts, part, j0, j1);     // j = j0 .. j1-1
+    if (j0 >= j1) return;
+    int d = LT_NODE(L, j0 - 1);
+    int d2 = (d * (d - 1)) >> 1;
+    auto group = [&](int j, int tj, double ej, auto ucount) {     // tj / ej: the register slot holding positions j .. j+U-1
+        constexpr int U = decltype(ucount)::value;
+        double vac[U], vbd[U], ecd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = bcast_int(tj, j + u);
+            const int c2 = (c * (c - 1)) >> 1;
+            ecd[u] = bcast_f64(ej, j + u);                   // D[c,d]
+            vac[u] = s.dist_at(s.idx2(a, a2, c, c2));        // D[a,c]
+            vbd[u] = s.dist_at(s.idx2(b, b2, d, d2));        // D[b,d]
+            d = c; d2 = c2;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
+            delta = delta - eab;
+            delta = delta - ecd[u];
+            if (row_ok && j + u >= i + 2 && delta < bd) {
+                if (!close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
+            }
+        }
+    };
+    using U4 = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using U1 = std::integral_constant<int, 1>;
+    const int ja = j1 < kWave ? j1 : kWave;                  // slot 0: j in [j0, ja)
+    int j = j0;
+    for (; j + GLS_LEAN_UNROLL <= ja; j += GLS_LEAN_UNROLL) group(j, L.t0, L.e0, U4{});
+    for (; j < ja; ++j) group(j, L.t0, L.e0, U1{});
+    j = j0 > kWave ? j0 : kWave;                             // slot 1: j in [max(j0, 64), j1)
+    for (; j + GLS_LEAN_UNROLL <= j1; j += GLS_LEAN_UNROLL) group(j, L.t1, L.e1, U4{});
+    for (; j < j1; ++j) group(j, L.t1, L.e1, U1{});
+}
+
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
@@ -649,7 +849,7 @@ struct Trace<false> {
 
 template <class S, bool FI, class TT, class TRC>
 __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
-                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals) {
+                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
     build_edges(s, t, Ef, Eb, n, tid, nthr);
@@ -660,16 +860,29 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
+            bool lean = false;
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
             // software-pipelining the uniform operands one step ahead costs registers: 9.6k at TSP100
-            if (S::kScanUnroll == 1 && S::kSymmetric && n - 1 <= 2 * kWave) {
+            if constexpr (!FI && S::kSymmetric) {
+                // positions 0..n fit two register slots per lane; every block of 64 rows needs a wavefront of its own
+                if (n <= 2 * kWave - 1 && nwaves >= (n - 1 + kWave - 1) / kWave) {
+                    if (op == 0) scan_two_opt_a2a_lean<S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                    else         scan_relocate_a2a_lean<S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+                    lean = true;
+                }
+            }
+            if (lean) {
+            } else if (FI && S::kScanUnroll == 1 && S::kSymmetric && n - 1 <= 2 * kWave) {
                 if (op == 0) scan_two_opt_a2a_rowlane<S, FI, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                 else         scan_relocate_a2a_rowlane<S, FI, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             } else {
                 if (op == 0) scan_two_opt_a2a<S, FI, TT, S::kScanUnroll>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                 else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             }
+            STAMP_END(8);    // a2a scan (this wave's share)
             block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
+            STAMP_END(9);    // wave + workgroup arg-min (includes waiting for the slowest wave)
+            STAMP_COUNT(11);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
                 improved = true;
@@ -678,9 +891,327 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
                 TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();
+                STAMP_END(10);   // move application + barrier
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Perturbation phase (algorithms.py:150-185), fused form for the symmetric (LDS-triangle) stores.  Wavefront 0 only.
+// ---------------------------------------------------------------------------------------------
+// The reference runs, per penalised edge, up to four one-to-all scans on the guided matrix G = D + k*P: for each
+// endpoint position i: two_opt_o2a(i), then relocate_o2a(i) (algorithms.py:167-174).  Evaluated one after the other they
+// are a chain of dependent memory round trips (tour bytes -> indices -> penalties in L1/L2 + distances in LDS), eight
+// of them per step at TSP100 (4 scans x 2 passes of 64 lanes), on the single wavefront that carries the instance.
+// Here lane l owns the GP CONSECUTIVE tour positions p = GP*l + q and keeps per position, in registers,
+//     tq = t[p]      dq = D[t[p], t[p+1]]      gq = guide[t[p], t[p+1]]      pq = P[t[p], t[p+1]]
+// (reloaded after a move).  Every operand of both scans at endpoint i is then one of
+//     GE[p] = dq + k*pq                 guided length of tour edge p            (registers, no memory)
+//     X[p]  = G[t[i],   t[p]]           one penalty load + one distance read per position
+//     Y[p]  = G[t[i-1], t[p]]           one penalty load + one distance read per position
+// or a neighbour position's value (own register for q +- 1 inside the lane, one DPP wave shift across lanes):
+//     two_opt  j = p > i : ((X[p] + Y[p-1]) - GE[i-1]) - GE[p-1]        j = p < i : ((X[p] + Y[p-1]) - GE[p-1]) - GE[i-1]
+//     relocate j = p > i : ((base - GE[p]) + X[p]) + X[p+1]             j = p < i : ((base - GE[p-1]) + X[p-1]) + X[p]
+//     base = ((-GE[i-1]) - GE[i]) + Y[i+1]
+// which are the reference's expressions term by term, in its operand order (operators.py:17-28,88-102; G symmetric bit
+// for bit because D and P are).  So ONE round of loads serves both scans of an endpoint for all positions at once; the
+// relocate candidates are computed speculatively and are exact whenever two_opt_o2a accepted nothing (95 % of the
+// scans); after an accepted two_opt move the pass is repeated for relocate_o2a on the new tour with the SAME i (the
+// reference's stale index, algorithms.py:169-174).  Two dependent round trips per step instead of eight.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shift_f64(double fill, double v) {     // lanes without a source keep `fill`
+    const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+constexpr int kDppWaveShl1 = 0x130;    // lane l reads lane l + 1
+constexpr int kDppWaveShr1 = 0x138;    // lane l reads lane l - 1
+
+template <class S, bool FI, int GP, bool TR, class TT, class TRC>
+__device__ __forceinline__ void perturb_fused(const S &s, const GlsArgs &A, const double *guide, double k, TT *&t, TT *&t2,
+                                              double *Ef, double *Eb, int n, int lane, long long t_start, TRC &tr,
+                                              long long &evals, int &status, double &cur_cost, bool &any_moved, Stamps &st) {
+    int moves = 0;
+    long long steps = 0;
+    int tq[GP], pq[GP];
+    double dq[GP], gq[GP];
+    auto reload = [&]() {
+        int tn[GP + 1];
+#pragma unroll
+        for (int q = 0; q < GP; ++q) { const int p = GP * lane + q; tq[q] = p <= n ? (int)t[p] : 0; tn[q] = tq[q]; }
+        tn[GP] = __builtin_amdgcn_update_dpp(0, tq[0], kDppWaveShl1, 0xf, 0xf, false);    // t[GP*(lane+1)]
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int p = GP * lane + q;
+            const bool live = p < n;                                  // tour edge p = (t[p], t[p+1]) exists
+            const int u = tn[q], v = live ? tn[q + 1] : (u == 0 ? 1 : 0);          // dead slots read a harmless entry
+            const int qi = s.idx(u, v);
+            dq[q] = s.dist_at(qi);
+            pq[q] = s.pen_at(qi);
+            gq[q] = guide[(size_t)u * n + v];
+        }
+    };
+    reload();
+    while (moves < A.perturbation_moves) {
+        // ---- arg-max utility over tour edges, first maximum wins (algorithms.py:153-159) ----
+        double bu = 0.0; int bp = kNoKey;
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int p = GP * lane + q;
+            if (p < n) {
+                const double util = gq[q] / (1.0 + (double)pq[q]);
+                if (bp == kNoKey || util > bu) { bu = util; bp = p; }
+            }
+        }
+        wave_argmax_first(bu, bp);
+        STAMP_END(0);   // utility arg-max
+        // ---- penalty += 1 (algorithms.py:161): the owning lane stores count + 1, nothing is read back ----
+        const int eu = t[bp], ev = t[bp + 1];                                  // wave-uniform (broadcast LDS reads)
+        bool ovf = false;
+#pragma unroll
+        for (int q = 0; q < GP; ++q)
+            if (bp == GP * lane + q) { ovf = s.pen_set(eu, ev, pq[q]); pq[q] += 1; }
+        if (__ballot(ovf) != 0ull) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
+        bool moved_this_step = false;
+        for (int side = 0; side < 2; ++side) {                                 // algorithms.py:167
+            const int node = side == 0 ? eu : ev;
+            if (node == 0) continue;                                           // algorithms.py:168
+            int i = bp + side;                                                 // algorithms.py:169: index(n); searched only after a move
+            if (moved_this_step) {
+                unsigned long long m = 0ull;
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    const unsigned long long mq = __ballot(GP * lane + q <= n && tq[q] == node);
+                    if (m == 0ull && mq != 0ull) { m = mq; i = GP * (__ffsll((long long)mq) - 1) + q; }
+                }
+                // first occurrence: the depot is the only node that appears twice and it is never searched for
+            }
+            for (int first_op = 0; first_op < 2;) {                            // algorithms.py:171: two_opt_o2a, then relocate_o2a
+                const int ti = t[i], tim = t[i - 1];                           // wave-uniform (broadcast LDS reads)
+                // ---- one round of loads: X[p] = G[t[i], t[p]], Y[p] = G[t[i-1], t[p]] for the lane's positions ----
+                int qx[GP], qy[GP], px[GP], py[GP];
+                double x[GP], y[GP], ge[GP];
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    qx[q] = tq[q] == ti ? 0 : s.idx(ti, tq[q]);               // (a, a) is not a triangle entry: read entry 0, unused
+                    qy[q] = tq[q] == tim ? 0 : s.idx(tim, tq[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < GP; ++q) { px[q] = s.pen_at(qx[q]); py[q] = s.pen_at(qy[q]); }
+#pragma unroll
+                for (int q = 0; q < GP; ++q) { x[q] = s.dist_at(qx[q]); y[q] = s.dist_at(qy[q]); }
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    ge[q] = dq[q] + k * (double)pq[q];                         // [exact] product rounded, then sum (algorithms.py:164)
+                    x[q] = x[q] + k * (double)px[q];
+                    y[q] = y[q] + k * (double)py[q];
+                }
+                STAMP_END(12);  // tour nodes -> indices -> penalties + distances -> guided values
+                // neighbour positions: p - 1 of the lane's first position, p + 1 of its last one
+                const double x_prev = dpp_shift_f64<kDppWaveShr1>(0.0, x[GP - 1]);
+                const double y_prev = dpp_shift_f64<kDppWaveShr1>(0.0, y[GP - 1]);
+                const double ge_prev = dpp_shift_f64<kDppWaveShr1>(0.0, ge[GP - 1]);
+                const double x_next = dpp_shift_f64<kDppWaveShl1>(0.0, x[0]);
+                // wave-uniform terms, taken from the lane that owns the position
+                auto uniform_of = [&](const double (&arr)[GP], int p) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int q = 0; q < GP; ++q) if ((p % GP) == q) r = bcast_f64(arr[q], p / GP);
+                    return r;
+                };
+                const double ge_im = uniform_of(ge, i - 1);                    // G[t[i-1], t[i]]
+                for (int op = first_op; op < 2; ++op) {
+                    double bd = 0.0; int bk = kNoKey;
+                    if (op == 0) {
+#pragma unroll
+                        for (int q = 0; q < GP; ++q) {
+                            const int p = GP * lane + q;
+                            int dj = i - p; if (dj < 0) dj = -dj;
+                            const double yp = q == 0 ? y_prev : y[q > 0 ? q - 1 : 0];
+                            const double gp = q == 0 ? ge_prev : ge[q > 0 ? q - 1 : 0];
+                            double delta = x[q] + yp;                          // operators.py:25-28, left to right
+                            if (p > i) { delta = delta - ge_im; delta = delta - gp; }
+                            else       { delta = delta - gp; delta = delta - ge_im; }
+                            if (p >= 1 && p <= n - 1 && dj >= 2) consider<FI>(delta, p, bd, bk);   // operators.py:59-62
+                        }
+                    } else {
+                        const double ge_i = uniform_of(ge, i);                 // G[t[i], t[i+1]]
+                        const double y_ip = uniform_of(y, i + 1);              // G[t[i-1], t[i+1]]
+                        double base = -ge_im;                                  // operators.py:97-99, left to right
+                        base = base - ge_i;
+                        base = base + y_ip;
+#pragma unroll
+                        for (int q = 0; q < GP; ++q) {
+                            const int p = GP * lane + q;
+                            const double xm = q == 0 ? x_prev : x[q > 0 ? q - 1 : 0];
+                            const double xp = q == GP - 1 ? x_next : x[q < GP - 1 ? q + 1 : 0];
+                            const double gm = q == 0 ? ge_prev : ge[q > 0 ? q - 1 : 0];
+                            double delta;
+                            if (p > i) { delta = base - ge[q]; delta = delta + x[q]; delta = delta + xp; }   // d=t[j], e=t[j+1]
+                            else       { delta = base - gm;    delta = delta + xm;   delta = delta + x[q]; } // d=t[j-1], e=t[j]
+                            if (p >= 1 && p <= n - 1 && p != i) consider<FI>(delta, p, bd, bk);   // operators.py:112-115
+                        }
+                    }
+                    STAMP_END(1);   // round of loads + candidates
+                    if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
+                    STAMP_END(2);   // reduction
+                    if (lane == 0) evals += (op == 0) ? (n - 3) : (n - 2);
+                    first_op = op + 1;
+                    if (bk != kNoKey) {                                        // algorithms.py:175
+                        apply_move(s, t, t2, Ef, Eb, n, op, i, bk, lane, kWave, TR);
+                        TT *xch = t; t = t2; t2 = xch;
+                        wave_sync();
+                        any_moved = true;
+                        moved_this_step = true;
+                        moves += 1;                                            // algorithms.py:185
+                        reload();
+                        if (TR) {
+                            cur_cost = tour_cost_from_edges(Ef, n);            // algorithms.py:176
+                            if (lane == 0) tr.push(cur_cost);
+                        } else if (lane == 0) {
+                            tr.len++;                                          // move counted, cost deferred
+                        }
+                        STAMP_END(3);   // apply move + reload
+                        break;              // the relocate candidates of this round are stale: new round, same i
+                    }
+                }
+            }
+        }
+        steps++;
+        STAMP_COUNT(6);
+        if ((steps & 63) == 0) {
+            const long long el = wall_clock64() - t_start;
+            if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Perturbation phase (algorithms.py:150-185), parallel speculative form.  All wavefronts of the workgroup take part.
+// ---------------------------------------------------------------------------------------------
+// Per penalised edge the reference runs up to four one-to-all scans in sequence: two_opt_o2a and relocate_o2a at the
+// first endpoint, then at the second (algorithms.py:167-174).  On one wavefront that is the serial chain that limits an
+// instance (each scan: tour bytes -> indices -> penalties in L1/L2 + distances in LDS -> arg-min, ~2.3k cycles).  A scan
+// only READS the tour, so here wavefronts 0..3 evaluate scans 0..3 concurrently on the current tour; the results are
+// then consumed in the reference's order and are exact up to (and including) the first scan that accepts a move.  That
+// move is applied and the scans after it are evaluated again on the new tour (82 % of the first scans and about half
+// of all scans accept nothing: ~2 rounds per step instead of 4 scans).  The position index of an endpoint follows the
+// reference: `i = cur_tour.index(n)` is taken when its first scan is consumed and is reused, stale, by its second scan
+// (algorithms.py:169-174); speculative scans of the second endpoint use the index it has on the tour they read.
+// Wavefront 0 alone does the utility arg-max and the penalty update (register-cached utilities).
+template <class S, bool FI, int GP, bool TR, class TT, class TRC>
+__device__ __forceinline__ void perturb_parallel(const S &s, const GlsArgs &A, const double *guide, double k, TT *&t, TT *&t2,
+                                                 double *Ef, double *Eb, int n, Ctl *ctl, int &phase, long long t_start,
+                                                 TRC &tr, long long &evals, int &status, double &cur_cost, bool &any_moved,
+                                                 Stamps &st) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    int moves = 0;
+    long long steps = 0;
+    double gq[GP];
+    int pq[GP];
+    auto reload_guides = [&]() {                  // wavefront 0: utilities of the tour edges, lane p holds positions p, p+64, ...
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int p = lane + q * kWave;
+            if (p < n) { const int u = t[p], v = t[p + 1]; gq[q] = guide[(size_t)u * n + v]; pq[q] = s.pen(u, v); }
+        }
+    };
+    if (wave == 0) { __builtin_amdgcn_s_setprio(3); reload_guides(); }
+    while (moves < A.perturbation_moves) {
+        // ---- wavefront 0: arg-max utility (first maximum wins, algorithms.py:153-159) and penalty += 1 (:161) ----
+        if (wave == 0) {
+            double bu = 0.0; int bp = kNoKey;
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const int p = lane + q * kWave;
+                if (p < n) {
+                    const double util = gq[q] / (1.0 + (double)pq[q]);
+                    if (bp == kNoKey || util > bu) { bu = util; bp = p; }
+                }
+            }
+            wave_argmax_first(bu, bp);
+            const int eu0 = t[bp], ev0 = t[bp + 1];
+            bool ovf = false;
+#pragma unroll
+            for (int q = 0; q < GP; ++q)
+                if (bp == lane + q * kWave) { ovf = s.pen_set(eu0, ev0, pq[q]); pq[q] += 1; }
+            int word = bp;
+            if (__ballot(ovf) != 0ull) word = -2;                              // counter overflow: stop this instance
+            if ((steps & 63) == 63 && wall_clock64() - t_start > (long long)(A.watchdog_s * 1e8)) word = -1;
+            if (lane == 0) ctl->flag = word;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the penalty store precedes the other waves' loads
+            STAMP_END(0);   // utility arg-max + penalty update
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int bp = ctl->flag;
+        if (bp < 0) { status = bp == -1 ? GNNGLS_STATUS_WATCHDOG_DEV : GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
+        const int eu = t[bp], ev = t[bp + 1];
+        bool moved_this_step = false;
+        int i_cur = 0;                                                         // index of the endpoint whose scans are being consumed
+        int next = 0;                                                          // first scan (0..3 = side*2 + op) not yet consumed
+        while (next < 4) {
+            // ---- speculative round: wavefront w evaluates scan w (if it is still to be consumed) on the current tour ----
+            double bd = 0.0; int bk = kNoKey; int iw = 0;
+            if (wave < 4 && wave >= next) {
+                const int side = wave >> 1, node = side == 0 ? eu : ev;
+                if (node != 0) {                                               // algorithms.py:168
+                    if ((next & 1) == 1 && side == (next >> 1)) iw = i_cur;    // second scan of the endpoint in progress: stale index
+                    else if (!moved_this_step) iw = bp + side;                 // the edge was read at positions bp, bp+1
+                    else {
+                        for (int p0 = 0; p0 <= n; p0 += kWave) {               // algorithms.py:169 cur_tour.index(n)
+                            const int p = p0 + lane;
+                            const unsigned long long m = __ballot(p <= n && t[p] == node);
+                            if (m) { iw = p0 + __ffsll((long long)m) - 1; break; }
+                        }
+                    }
+                    if ((wave & 1) == 0) scan_two_opt_o2a_guided<S, FI>(s, k, t, n, iw, lane, bd, bk);
+                    else                 scan_relocate_o2a_guided<S, FI>(s, k, t, n, iw, lane, bd, bk);
+                    if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
+                }
+                if (lane == 0) { ctl->red_d[phase][wave] = bd; ctl->red_k[phase][wave] = bk; ctl->red_k[phase][4 + wave] = iw; }
+            }
+            if (wave == 0) STAMP_END(1);   // scan round (wavefront 0's view)
+            __syncthreads();
+            // ---- consume the results in the reference's order (every wavefront takes the same decisions) ----
+            int s_move = -1;
+            for (int sc = next; sc < 4; ++sc) {
+                const int node = (sc >> 1) == 0 ? eu : ev;
+                if (node == 0) continue;
+                if (tid == 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
+                if ((sc & 1) == 0) i_cur = ctl->red_k[phase][4 + sc];          // first scan of an endpoint fixes its index
+                if (ctl->red_k[phase][sc] != kNoKey) { s_move = sc; break; }
+            }
+            const int mj = s_move >= 0 ? ctl->red_k[phase][s_move] : 0;
+            const int mi = s_move >= 0 ? ctl->red_k[phase][4 + s_move] : 0;
+            phase ^= 1;
+            if (wave == 0) STAMP_END(2);   // barrier + decision
+            if (s_move < 0) break;
+            apply_move(s, t, t2, Ef, Eb, n, s_move & 1, mi, mj, tid, nthr, TR);   // algorithms.py:175
+            { TT *x = t; t = t2; t2 = x; }
+            __syncthreads();
+            any_moved = true;
+            moved_this_step = true;
+            moves += 1;                                                        // algorithms.py:185
+            if (wave == 0) {
+                reload_guides();
+                if (TR) {
+                    cur_cost = tour_cost_from_edges(Ef, n);                    // algorithms.py:176
+                    if (lane == 0) tr.push(cur_cost);
+                } else if (lane == 0) {
+                    tr.len++;                                                  // move counted, cost deferred
+                }
+                STAMP_END(3);   // apply move + reload
+            }
+            next = s_move + 1;
+        }
+        steps++;
+        if (wave == 0) STAMP_COUNT(6);
+    }
+    if (wave == 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
@@ -765,7 +1296,8 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
     };
     if (tid == 0 && A.imp_len) A.imp_len[b] = 0;
 
-    local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);   // algorithms.py:142
+    STAMP_BEGIN();
+    local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
@@ -788,14 +1320,33 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (!ctl->flag) break;
         const double *guide = A.guides + ((size_t)(iter_i % A.n_guides) * A.B + b) * nn;   // algorithms.py:147
 
-        // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
-        if (wave == 0) {
+        // ---- perturbation (algorithms.py:150-185) ----
+        bool par_moved = false;
+        const bool parallel_perturb = GLS_PARALLEL_PERTURB && S::kSymmetric && (nthr >> 6) >= 4;
+        if (parallel_perturb) {      // four wavefronts evaluate the four one-to-all scans of a step speculatively
+            STAMP_BEGIN();
+            perturb_parallel<S, FI, GP, TR>(s, A, guide, k, t, t2, Ef, Eb, n, ctl, phase, t_start, tr, evals, status, cur_cost,
+                                            par_moved, st);
+        }
+        if (wave == 0 && parallel_perturb) {
+            if (par_moved && !eager_cost) {
+                build_edges(s, t, Ef, Eb, n, lane, kWave);
+                wave_sync();
+                cur_cost = tour_cost_from_edges(Ef, n);
+            }
+            if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
+            STAMP_END(4);       // phase tail
+        }
+        if (wave == 0 && !parallel_perturb) {     // wavefront 0 only (small workgroups, global-memory store)
             STAMP_BEGIN();
             // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
             // waves of the other resident workgroups on the same SIMD: give it priority while it runs
             __builtin_amdgcn_s_setprio(3);
-            int moves = 0;
             bool any_moved = false;
+            if constexpr (S::kSymmetric && GLS_FUSED_PERTURB) {
+                perturb_fused<S, FI, GP, TR>(s, A, guide, k, t, t2, Ef, Eb, n, lane, t_start, tr, evals, status, cur_cost, any_moved, st);
+            } else {
+            int moves = 0;
             long long steps = 0;
             // utility numerators of the current tour edges, G.edges[e][guide] (algorithms.py:155), cached in
             // registers: lane p holds positions p, p+64, ... ; reloaded (asynchronously -- the values are only
@@ -835,21 +1386,30 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                 STAMP_END(0);   // utility arg-max
                 const int eu = t[bp], ev = t[bp + 1];
                 bool ovf = false;
-                if (lane == 0) ovf = s.pen_inc(eu, ev);                        // algorithms.py:161
-                if (__builtin_amdgcn_readfirstlane((int)ovf)) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
                 if (greg) {
+                    // algorithms.py:161.  The lane that caches tour edge bp holds its current count: it stores count + 1
+                    // itself, so the serial chain has no load -> add -> store round trip through L1/L2
 #pragma unroll
-                    for (int q = 0; q < GP; ++q) if (bp == lane + q * kWave) pq[q] += 1;
+                    for (int q = 0; q < GP; ++q)
+                        if (bp == lane + q * kWave) { ovf = s.pen_set(eu, ev, pq[q]); pq[q] += 1; }
+                    ovf = __ballot(ovf) != 0ull;
+                } else {
+                    if (lane == 0) ovf = s.pen_inc(eu, ev);
+                    ovf = __builtin_amdgcn_readfirstlane((int)ovf) != 0;
                 }
+                if (ovf) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
                 wave_sync();
+                bool moved_this_step = false;
                 for (int side = 0; side < 2; ++side) {                         // algorithms.py:167
                     const int node = side == 0 ? eu : ev;
                     if (node == 0) continue;                                   // algorithms.py:168
-                    int i = 0;                                                 // algorithms.py:169
-                    for (int p0 = 0; p0 <= n; p0 += kWave) {
-                        int p = p0 + lane;
-                        unsigned long long m = __ballot(p <= n && t[p] == node);
-                        if (m) { i = p0 + __ffsll((long long)m) - 1; break; }
+                    int i = bp + side;                                         // algorithms.py:169 cur_tour.index(n): the edge was read
+                    if (moved_this_step) {                                     // at positions bp, bp+1; search only after a move
+                        for (int p0 = 0; p0 <= n; p0 += kWave) {
+                            int p = p0 + lane;
+                            unsigned long long m = __ballot(p <= n && t[p] == node);
+                            if (m) { i = p0 + __ffsll((long long)m) - 1; break; }
+                        }
                     }
 #pragma unroll 1
                     for (int op = 0; op < 2; ++op) {                           // algorithms.py:171
@@ -867,6 +1427,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                             TT *x = t; t = t2; t2 = x;
                             wave_sync();
                             any_moved = true;
+                            moved_this_step = true;
                             moves += 1;                                        // algorithms.py:185
                             reload_guides();
                             if (eager_cost) {
@@ -886,6 +1447,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                     if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
                 }
             }
+            }   // !kSymmetric
             if (any_moved && !eager_cost) {
                 build_edges(s, t, Ef, Eb, n, lane, kWave);
                 wave_sync();
@@ -905,7 +1467,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals);
+        local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -935,7 +1497,7 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (A.evals) A.evals[b] = evals;
         if (A.status) A.status[b] = status;
 #ifdef GLS_STAMPS
-        if (A.stamps) { long long *o = A.stamps + (size_t)b * 8; for (int q = 0; q < 8; ++q) o[q] = st_acc[q]; }
+        if (A.stamps) { long long *o = A.stamps + (size_t)b * 16; for (int q = 0; q < 16; ++q) o[q] = st.acc[q]; }
 #endif
     }
     if (A.penalty_out) {
@@ -1055,7 +1617,11 @@ size_t gls_lds_bytes(int n, int store, int penalty_bits) {
     return off;
 }
 
+static int g_threads_override = 0;      // experiments only (gnngls_debug_set_gls_threads)
+void gls_set_block_threads_override(int threads) { g_threads_override = threads; }
+
 int gls_block_threads(int n, int store) {
+    if (g_threads_override > 0) return g_threads_override;
     if (n <= 24) return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
@@ -1064,6 +1630,7 @@ int gls_block_threads(int n, int store) {
     //   4 waves, 128 VGPRs, no spills, descent scans batched 4-deep for ILP  7.4k
     //   6 or 7 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (3 resident only)
     //   5 waves at <= 80 VGPRs (no spills) pack and reach 9.6k vs 9.9k for 8 waves; at 85+ VGPRs they no longer pack
+    if (store == GLS_STORE_COMPACT) return GLS_COMPACT_THREADS;
     return 512;
 }
 
@@ -1088,7 +1655,7 @@ static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStr
 template <class S, bool FI>
 static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
     // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover n <= 128
-    if (A.n <= 2 * kWave) return launch_gls_g<S, FI, 2>(A, lds, threads, stream);
+    if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2>(A, lds, threads, stream);
     return launch_gls_g<S, FI, kGuidePassesMax>(A, lds, threads, stream);
 }
 

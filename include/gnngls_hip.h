@@ -187,7 +187,11 @@ int gnngls_unpack_regret(const float *y, int B, int n, double scale, double min_
  * the overflow -> rerun-with-32-bit path can be exercised in seconds.  Never called by the product. */
 int gnngls_debug_set_penalty16_limit(int limit);
 
-/* Diagnostic hook: device buffer of 8 int64 per instance that a library built with -DGLS_STAMPS fills with
+/* Experiment hook: forces the workgroup size of gnngls_gls_run (64, 128, 256 or 512 threads; 0 = the default policy by
+ * instance size).  Used by scripts/probe_gls.py to measure the policy; never called by the product. */
+int gnngls_debug_set_gls_threads(int threads);
+
+/* Diagnostic hook: device buffer of 16 int64 per instance that a library built with -DGLS_STAMPS fills with
  * per-phase shader-cycle totals of gnngls_gls_run (scripts/probe_gls_stamps.py).  Ignored by normal builds. */
 int gnngls_debug_set_stamp_buffer(void *device_buffer);
 

@@ -13,8 +13,10 @@ the value kept per instance is the MINIMUM tour length over independent long sea
     guide list ['weight', 'regret_pred']
   * block 0, first `oracle_instances` instances: the CPU oracle (oracle/gls_oracle.c) for `seconds`, one instance per host
     core, guide 'weight'
-Tour lengths are recomputed with tour_cost (left-to-right fp64 sum) from the returned tours, never taken from the
-searches' own bookkeeping.  The file records how every block was made; bench.py only ever reads it.
+GPU tour lengths are recomputed with tour_cost (left-to-right fp64 sum) from the returned tours, never taken from the
+searches' own bookkeeping; the CPU-oracle leg contributes its returned best_cost (the reference's incremental sum,
+algorithms.py:124,190 -- the same tour can differ from tour_cost by an ulp, which is why that leg "wins" ties at the
+1e-15 level).  The file records how every block was made (`how`, `log`, `winner*`); bench.py only ever reads it.
 """
 import argparse
 import json

@@ -11,21 +11,33 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()
 init = ops.nearest_neighbor(D); cost = ops.tour_cost(init, D)
+g = D[None].contiguous()
+if len(sys.argv) > 3 and sys.argv[3] == "noise":
+    x = np.maximum(np.random.default_rng(1).normal(0.05, 0.1, size=(B, n, n)).astype(np.float32).astype(np.float64), 0)
+    x = np.triu(x, 1)
+    g = torch.from_numpy((x + x.transpose(0, 2, 1))[None]).cuda().contiguous()
+    init = ops.nearest_neighbor(g[0]); cost = ops.tour_cost(init, D)
 # the stamp sink is a side buffer registered through the debug hook of the C ABI;
 # trace_cap=0 = the throughput path (trace-free kernel instantiation, deferred tour_cost)
 from gnngls_amd import _lib
-stamps = torch.zeros((B, 8), dtype=torch.int64, device="cuda")
+stamps = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
 _lib.check(_lib.load().gnngls_debug_set_stamp_buffer(_lib.ptr(stamps)))
 tc = int(os.environ.get("TRACE_CAP", "0"))
-r = ops.gls_run(D, D[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
+r = ops.gls_run(D, g, init, cost, penalty_bits=int(os.environ.get('BITS', '0')), perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
 torch.cuda.synchronize()
 st = stamps.double().mean(0).cpu().numpy()
 assert st.sum() > 0, 'library was not built with GNNGLS_EXTRA_FLAGS=-DGLS_STAMPS'
 names = ["utility argmax", "o2a scan (+pen, pos search)", "o2a reduce", "apply+reload", "phase tail", "descent (LS)", "steps"]
+st[1] += st[12]
+st[5] += st[8] + st[9] + st[10]          # the descent's sub-stamps restart the clock: slot 5 only holds the remainder
 tot = st[:6].sum()
 it = r.outer_iters.double().mean().item()
 print(f"outer iters {it:.0f}, perturbation steps/iter {st[6] / it:.1f}")
 for k in range(6):
     print(f"{names[k]:30s} {st[k] / tot * 100:5.1f}%   {st[k] / it:9.0f} cycles/outer-iter")
 print(f"cycles per perturbation step (wave 0): {(st[0] + st[1] + st[2] + st[3]) / st[6]:.0f}")
+print(f"descent: scans/iter {st[11] / it:.2f}; per scan: scan {st[8] / st[11]:.0f}, arg-min+wait {st[9] / st[11]:.0f}, "
+      f"apply+barrier {st[10] / st[11]:.0f} cycles (share of descent {100 * (st[8] + st[9] + st[10]) / max(st[5], 1):.0f}%)")
+print(f"fused rounds: load part {st[12] / it:.0f} cycles/iter")
+print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
