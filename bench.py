@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100, help="TSP nodes per instance")
+    # --tsp_n: the spelling to use under torchrun (its own parser rejects `--n` as an ambiguous prefix of --nnodes ...)
+    ap.add_argument("--n", "--tsp_n", dest="n", type=int, default=100, help="TSP nodes per instance")
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (weak scaling)")
     ap.add_argument("--total_instances", type=int, default=0,
                     help="strong scaling: a fixed test set of this many instances sharded over the ranks (configs[3]: 10000)")
@@ -152,10 +153,28 @@ def load_traffic():
     return merged
 
 
+def available_cores():
+    """CPUs this process may actually use: min(online CPUs, scheduler affinity, cgroup CPU quota).  On the GPU boxes the
+    container sees 256 hardware threads but its cgroup grants 16 CPUs; more worker processes than that only time-slice."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, cores):
     """The CPU oracle (oracle/gls_oracle.c, the parity-pinned restatement of the reference's
-    guided_local_search) timed on ALL host cores of this box: one instance per core (the reference is single-threaded,
-    test.py:59), same instances, same budget, in child processes.  Bounded sample: `cores` instances, one budget."""
+    guided_local_search) timed on ALL CPUs available to this container (available_cores()): one instance per core (the
+    reference is single-threaded, test.py:59), same instances, same budget, in child processes.  Bounded sample: `cores`
+    instances, one budget."""
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "sample.npz")
         np.savez(path, D=D, guides=guides, init_tour=init_tour, init_cost=init_cost)
@@ -170,9 +189,10 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, co
     search = float(np.mean([o["search_s"] for o in outs]))
     return {"value": cores / wall, "unit": "instances/s", "cores": cores, "kind": "port",
             "per_core_value": 1.0 / search,
-            "sample": f"{cores} TSP{D.shape[1]} instances of the same batch, one per host core on all {os.cpu_count()} "
-                      f"host cores, {time_limit:g} s search budget each (GNN forward not charged to the CPU), guides as on "
-                      f"the GPU; value = whole host incl. process start-up, per_core_value = 1 / mean search time",
+            "sample": f"{cores} TSP{D.shape[1]} instances of the same batch, one per core on all {available_cores()} CPUs "
+                      f"available to this container (cgroup quota; the box has {os.cpu_count()} hardware threads), "
+                      f"{time_limit:g} s search budget each (GNN forward not charged to the CPU), guides as on "
+                      f"the GPU; value = all available cores incl. process start-up, per_core_value = 1 / mean search time",
             "mean_gap_pct": float(gaps.mean()) if gaps is not None else None,
             "outer_iters_per_instance": float(np.mean([o["outer_iters"] for o in outs])),
             "delta_evals_per_s": float(sum(o["evals"] for o in outs) / search),
@@ -350,7 +370,7 @@ def main():
             "kernels": kern, "forward_kernels_ms_total": fwd_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = max(1, min(args.cpu_cores or (os.cpu_count() or 1), B))
+            cores = max(1, min(args.cpu_cores or available_cores(), B))
             Ds = D[:cores].contiguous()
             Rs = pipeline.predict_regret(model, Ds, scalers) if need_model else None
             guides_host = torch.stack([Rs if gname == "regret_pred" else Ds for gname in args.guides]).cpu().numpy()

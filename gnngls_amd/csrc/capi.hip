@@ -65,11 +65,11 @@ int num_cus() {
 
 // Storage configuration of the persistent search kernel for instances of n nodes: the one with the
 // most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
-struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; };
+struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; };
 
 GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
     GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, gnngls::gls_block_threads(n, gnngls::GLS_STORE_GLOBAL),
-                   gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0};
+                   gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0, 4};
     bool have = false, done = false;
     const int cus = num_cus();
     // candidates are visited fastest store first (LDS penalties 32-bit, LDS penalties 16-bit, compact); the first one
@@ -79,13 +79,16 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
         const int threads = gnngls::gls_block_threads(n, store);
-        // wave slots per CU at the kernel's register budget: 80 VGPRs -> 6 waves per SIMD (24 per CU);
-        // the compact-store variant is compiled for 64 VGPRs -> 8 per SIMD (32 per CU)
-        const int by_waves = (store == gnngls::GLS_STORE_COMPACT ? 32 : 24) / (threads / 64);
+        // wave slots per CU at the register budget of the kernel instantiation: LDS-penalty stores 80 VGPRs -> 6 waves
+        // per SIMD (24 per CU); compact store 128 VGPRs -> 4 per SIMD, or its 64-VGPR build -> 8 per SIMD when only that
+        // keeps the batch resident (and, without a batch size, for the capacity query)
+        int wps = gnngls::gls_waves_per_simd(store, n, batch, cus, threads, lds);
+        if (store == gnngls::GLS_STORE_COMPACT && batch <= 0) wps = 8;
+        const int by_waves = (wps * 4) / (threads / 64);
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;
-        if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu}; have = true; }
-        if (batch > 0 && (long)per_cu * cus >= batch) { pick = GlsConfig{store, bits, threads, lds, per_cu}; done = true; }
+        if (!have || per_cu > pick.per_cu) { pick = GlsConfig{store, bits, threads, lds, per_cu, wps}; have = true; }
+        if (batch > 0 && (long)per_cu * cus >= batch) { pick = GlsConfig{store, bits, threads, lds, per_cu, wps}; done = true; }
     };
     if (requested_bits == -2) {               // forced compact store (falls through to the global store if it cannot fit)
         if (n <= 255) consider(gnngls::GLS_STORE_COMPACT, 32);
@@ -217,7 +220,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     hipError_t e;
     {
         ProfScope ps(GNNGLS_PROF_GLS, st);
-        e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, first_improvement != 0, st);
+        e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, cfg.wps, first_improvement != 0, st);
     }
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");

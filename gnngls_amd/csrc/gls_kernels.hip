@@ -40,17 +40,8 @@
 
 namespace gnngls {
 
-#ifndef GLS_FUSED_PERTURB
-#define GLS_FUSED_PERTURB 0          // 0: the scan-after-scan perturbation phase (kept for the global store and for A/B runs)
-#endif
-#ifndef GLS_PARALLEL_PERTURB
-#define GLS_PARALLEL_PERTURB 1       // workgroups of >= 4 wavefronts: the four one-to-all scans of a step on four wavefronts
-#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
-#endif
-#ifndef GLS_COMPACT_THREADS
-#define GLS_COMPACT_THREADS 512      // workgroup size of the compact store for n > 80 (4 workgroups per CU at TSP100)
 #endif
 constexpr int kWave = 64;
 constexpr int kNoKey = INT_MAX;
@@ -144,8 +135,7 @@ struct TriDGlobalP {
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
     static constexpr bool kPenInLds = false;
-    // 4 workgroups per CU: 8 waves each -> 8 per SIMD (64 VGPRs); 4 waves each -> 4 per SIMD (128 VGPRs)
-    static constexpr int kWavesPerSimd = GLS_COMPACT_THREADS / 64;
+    static constexpr int kWavesPerSimd = 4;      // default register budget (128 VGPRs); the launcher also builds an 8-wave variant
     static constexpr int kScanUnroll = 1;        // measured: 2-deep batching costs more in spills than it hides (8.6k vs 10.0k)
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
@@ -897,327 +887,13 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Perturbation phase (algorithms.py:150-185), fused form for the symmetric (LDS-triangle) stores.  Wavefront 0 only.
-// ---------------------------------------------------------------------------------------------
-// The reference runs, per penalised edge, up to four one-to-all scans on the guided matrix G = D + k*P: for each
-// endpoint position i: two_opt_o2a(i), then relocate_o2a(i) (algorithms.py:167-174).  Evaluated one after the other they
-// are a chain of dependent memory round trips (tour bytes -> indices -> penalties in L1/L2 + distances in LDS), eight
-// of them per step at TSP100 (4 scans x 2 passes of 64 lanes), on the single wavefront that carries the instance.
-// Here lane l owns the GP CONSECUTIVE tour positions p = GP*l + q and keeps per position, in registers,
-//     tq = t[p]      dq = D[t[p], t[p+1]]      gq = guide[t[p], t[p+1]]      pq = P[t[p], t[p+1]]
-// (reloaded after a move).  Every operand of both scans at endpoint i is then one of
-//     GE[p] = dq + k*pq                 guided length of tour edge p            (registers, no memory)
-//     X[p]  = G[t[i],   t[p]]           one penalty load + one distance read per position
-//     Y[p]  = G[t[i-1], t[p]]           one penalty load + one distance read per position
-// or a neighbour position's value (own register for q +- 1 inside the lane, one DPP wave shift across lanes):
-//     two_opt  j = p > i : ((X[p] + Y[p-1]) - GE[i-1]) - GE[p-1]        j = p < i : ((X[p] + Y[p-1]) - GE[p-1]) - GE[i-1]
-//     relocate j = p > i : ((base - GE[p]) + X[p]) + X[p+1]             j = p < i : ((base - GE[p-1]) + X[p-1]) + X[p]
-//     base = ((-GE[i-1]) - GE[i]) + Y[i+1]
-// which are the reference's expressions term by term, in its operand order (operators.py:17-28,88-102; G symmetric bit
-// for bit because D and P are).  So ONE round of loads serves both scans of an endpoint for all positions at once; the
-// relocate candidates are computed speculatively and are exact whenever two_opt_o2a accepted nothing (95 % of the
-// scans); after an accepted two_opt move the pass is repeated for relocate_o2a on the new tour with the SAME i (the
-// reference's stale index, algorithms.py:169-174).  Two dependent round trips per step instead of eight.
-template <int CTRL>
-__device__ __forceinline__ double dpp_shift_f64(double fill, double v) {     // lanes without a source keep `fill`
-    const long long b = __double_as_longlong(v), f = __double_as_longlong(fill);
-    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)b, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), CTRL, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-constexpr int kDppWaveShl1 = 0x130;    // lane l reads lane l + 1
-constexpr int kDppWaveShr1 = 0x138;    // lane l reads lane l - 1
-
-template <class S, bool FI, int GP, bool TR, class TT, class TRC>
-__device__ __forceinline__ void perturb_fused(const S &s, const GlsArgs &A, const double *guide, double k, TT *&t, TT *&t2,
-                                              double *Ef, double *Eb, int n, int lane, long long t_start, TRC &tr,
-                                              long long &evals, int &status, double &cur_cost, bool &any_moved, Stamps &st) {
-    int moves = 0;
-    long long steps = 0;
-    int tq[GP], pq[GP];
-    double dq[GP], gq[GP];
-    auto reload = [&]() {
-        int tn[GP + 1];
-#pragma unroll
-        for (int q = 0; q < GP; ++q) { const int p = GP * lane + q; tq[q] = p <= n ? (int)t[p] : 0; tn[q] = tq[q]; }
-        tn[GP] = __builtin_amdgcn_update_dpp(0, tq[0], kDppWaveShl1, 0xf, 0xf, false);    // t[GP*(lane+1)]
-#pragma unroll
-        for (int q = 0; q < GP; ++q) {
-            const int p = GP * lane + q;
-            const bool live = p < n;                                  // tour edge p = (t[p], t[p+1]) exists
-            const int u = tn[q], v = live ? tn[q + 1] : (u == 0 ? 1 : 0);          // dead slots read a harmless entry
-            const int qi = s.idx(u, v);
-            dq[q] = s.dist_at(qi);
-            pq[q] = s.pen_at(qi);
-            gq[q] = guide[(size_t)u * n + v];
-        }
-    };
-    reload();
-    while (moves < A.perturbation_moves) {
-        // ---- arg-max utility over tour edges, first maximum wins (algorithms.py:153-159) ----
-        double bu = 0.0; int bp = kNoKey;
-#pragma unroll
-        for (int q = 0; q < GP; ++q) {
-            const int p = GP * lane + q;
-            if (p < n) {
-                const double util = gq[q] / (1.0 + (double)pq[q]);
-                if (bp == kNoKey || util > bu) { bu = util; bp = p; }
-            }
-        }
-        wave_argmax_first(bu, bp);
-        STAMP_END(0);   // utility arg-max
-        // ---- penalty += 1 (algorithms.py:161): the owning lane stores count + 1, nothing is read back ----
-        const int eu = t[bp], ev = t[bp + 1];                                  // wave-uniform (broadcast LDS reads)
-        bool ovf = false;
-#pragma unroll
-        for (int q = 0; q < GP; ++q)
-            if (bp == GP * lane + q) { ovf = s.pen_set(eu, ev, pq[q]); pq[q] += 1; }
-        if (__ballot(ovf) != 0ull) { status = GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
-        bool moved_this_step = false;
-        for (int side = 0; side < 2; ++side) {                                 // algorithms.py:167
-            const int node = side == 0 ? eu : ev;
-            if (node == 0) continue;                                           // algorithms.py:168
-            int i = bp + side;                                                 // algorithms.py:169: index(n); searched only after a move
-            if (moved_this_step) {
-                unsigned long long m = 0ull;
-#pragma unroll
-                for (int q = 0; q < GP; ++q) {
-                    const unsigned long long mq = __ballot(GP * lane + q <= n && tq[q] == node);
-                    if (m == 0ull && mq != 0ull) { m = mq; i = GP * (__ffsll((long long)mq) - 1) + q; }
-                }
-                // first occurrence: the depot is the only node that appears twice and it is never searched for
-            }
-            for (int first_op = 0; first_op < 2;) {                            // algorithms.py:171: two_opt_o2a, then relocate_o2a
-                const int ti = t[i], tim = t[i - 1];                           // wave-uniform (broadcast LDS reads)
-                // ---- one round of loads: X[p] = G[t[i], t[p]], Y[p] = G[t[i-1], t[p]] for the lane's positions ----
-                int qx[GP], qy[GP], px[GP], py[GP];
-                double x[GP], y[GP], ge[GP];
-#pragma unroll
-                for (int q = 0; q < GP; ++q) {
-                    qx[q] = tq[q] == ti ? 0 : s.idx(ti, tq[q]);               // (a, a) is not a triangle entry: read entry 0, unused
-                    qy[q] = tq[q] == tim ? 0 : s.idx(tim, tq[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < GP; ++q) { px[q] = s.pen_at(qx[q]); py[q] = s.pen_at(qy[q]); }
-#pragma unroll
-                for (int q = 0; q < GP; ++q) { x[q] = s.dist_at(qx[q]); y[q] = s.dist_at(qy[q]); }
-#pragma unroll
-                for (int q = 0; q < GP; ++q) {
-                    ge[q] = dq[q] + k * (double)pq[q];                         // [exact] product rounded, then sum (algorithms.py:164)
-                    x[q] = x[q] + k * (double)px[q];
-                    y[q] = y[q] + k * (double)py[q];
-                }
-                STAMP_END(12);  // tour nodes -> indices -> penalties + distances -> guided values
-                // neighbour positions: p - 1 of the lane's first position, p + 1 of its last one
-                const double x_prev = dpp_shift_f64<kDppWaveShr1>(0.0, x[GP - 1]);
-                const double y_prev = dpp_shift_f64<kDppWaveShr1>(0.0, y[GP - 1]);
-                const double ge_prev = dpp_shift_f64<kDppWaveShr1>(0.0, ge[GP - 1]);
-                const double x_next = dpp_shift_f64<kDppWaveShl1>(0.0, x[0]);
-                // wave-uniform terms, taken from the lane that owns the position
-                auto uniform_of = [&](const double (&arr)[GP], int p) {
-                    double r = 0.0;
-#pragma unroll
-                    for (int q = 0; q < GP; ++q) if ((p % GP) == q) r = bcast_f64(arr[q], p / GP);
-                    return r;
-                };
-                const double ge_im = uniform_of(ge, i - 1);                    // G[t[i-1], t[i]]
-                for (int op = first_op; op < 2; ++op) {
-                    double bd = 0.0; int bk = kNoKey;
-                    if (op == 0) {
-#pragma unroll
-                        for (int q = 0; q < GP; ++q) {
-                            const int p = GP * lane + q;
-                            int dj = i - p; if (dj < 0) dj = -dj;
-                            const double yp = q == 0 ? y_prev : y[q > 0 ? q - 1 : 0];
-                            const double gp = q == 0 ? ge_prev : ge[q > 0 ? q - 1 : 0];
-                            double delta = x[q] + yp;                          // operators.py:25-28, left to right
-                            if (p > i) { delta = delta - ge_im; delta = delta - gp; }
-                            else       { delta = delta - gp; delta = delta - ge_im; }
-                            if (p >= 1 && p <= n - 1 && dj >= 2) consider<FI>(delta, p, bd, bk);   // operators.py:59-62
-                        }
-                    } else {
-                        const double ge_i = uniform_of(ge, i);                 // G[t[i], t[i+1]]
-                        const double y_ip = uniform_of(y, i + 1);              // G[t[i-1], t[i+1]]
-                        double base = -ge_im;                                  // operators.py:97-99, left to right
-                        base = base - ge_i;
-                        base = base + y_ip;
-#pragma unroll
-                        for (int q = 0; q < GP; ++q) {
-                            const int p = GP * lane + q;
-                            const double xm = q == 0 ? x_prev : x[q > 0 ? q - 1 : 0];
-                            const double xp = q == GP - 1 ? x_next : x[q < GP - 1 ? q + 1 : 0];
-                            const double gm = q == 0 ? ge_prev : ge[q > 0 ? q - 1 : 0];
-                            double delta;
-                            if (p > i) { delta = base - ge[q]; delta = delta + x[q]; delta = delta + xp; }   // d=t[j], e=t[j+1]
-                            else       { delta = base - gm;    delta = delta + xm;   delta = delta + x[q]; } // d=t[j-1], e=t[j]
-                            if (p >= 1 && p <= n - 1 && p != i) consider<FI>(delta, p, bd, bk);   // operators.py:112-115
-                        }
-                    }
-                    STAMP_END(1);   // round of loads + candidates
-                    if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
-                    STAMP_END(2);   // reduction
-                    if (lane == 0) evals += (op == 0) ? (n - 3) : (n - 2);
-                    first_op = op + 1;
-                    if (bk != kNoKey) {                                        // algorithms.py:175
-                        apply_move(s, t, t2, Ef, Eb, n, op, i, bk, lane, kWave, TR);
-                        TT *xch = t; t = t2; t2 = xch;
-                        wave_sync();
-                        any_moved = true;
-                        moved_this_step = true;
-                        moves += 1;                                            // algorithms.py:185
-                        reload();
-                        if (TR) {
-                            cur_cost = tour_cost_from_edges(Ef, n);            // algorithms.py:176
-                            if (lane == 0) tr.push(cur_cost);
-                        } else if (lane == 0) {
-                            tr.len++;                                          // move counted, cost deferred
-                        }
-                        STAMP_END(3);   // apply move + reload
-                        break;              // the relocate candidates of this round are stale: new round, same i
-                    }
-                }
-            }
-        }
-        steps++;
-        STAMP_COUNT(6);
-        if ((steps & 63) == 0) {
-            const long long el = wall_clock64() - t_start;
-            if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Perturbation phase (algorithms.py:150-185), parallel speculative form.  All wavefronts of the workgroup take part.
-// ---------------------------------------------------------------------------------------------
-// Per penalised edge the reference runs up to four one-to-all scans in sequence: two_opt_o2a and relocate_o2a at the
-// first endpoint, then at the second (algorithms.py:167-174).  On one wavefront that is the serial chain that limits an
-// instance (each scan: tour bytes -> indices -> penalties in L1/L2 + distances in LDS -> arg-min, ~2.3k cycles).  A scan
-// only READS the tour, so here wavefronts 0..3 evaluate scans 0..3 concurrently on the current tour; the results are
-// then consumed in the reference's order and are exact up to (and including) the first scan that accepts a move.  That
-// move is applied and the scans after it are evaluated again on the new tour (82 % of the first scans and about half
-// of all scans accept nothing: ~2 rounds per step instead of 4 scans).  The position index of an endpoint follows the
-// reference: `i = cur_tour.index(n)` is taken when its first scan is consumed and is reused, stale, by its second scan
-// (algorithms.py:169-174); speculative scans of the second endpoint use the index it has on the tour they read.
-// Wavefront 0 alone does the utility arg-max and the penalty update (register-cached utilities).
-template <class S, bool FI, int GP, bool TR, class TT, class TRC>
-__device__ __forceinline__ void perturb_parallel(const S &s, const GlsArgs &A, const double *guide, double k, TT *&t, TT *&t2,
-                                                 double *Ef, double *Eb, int n, Ctl *ctl, int &phase, long long t_start,
-                                                 TRC &tr, long long &evals, int &status, double &cur_cost, bool &any_moved,
-                                                 Stamps &st) {
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & (kWave - 1), wave = tid >> 6;
-    int moves = 0;
-    long long steps = 0;
-    double gq[GP];
-    int pq[GP];
-    auto reload_guides = [&]() {                  // wavefront 0: utilities of the tour edges, lane p holds positions p, p+64, ...
-#pragma unroll
-        for (int q = 0; q < GP; ++q) {
-            const int p = lane + q * kWave;
-            if (p < n) { const int u = t[p], v = t[p + 1]; gq[q] = guide[(size_t)u * n + v]; pq[q] = s.pen(u, v); }
-        }
-    };
-    if (wave == 0) { __builtin_amdgcn_s_setprio(3); reload_guides(); }
-    while (moves < A.perturbation_moves) {
-        // ---- wavefront 0: arg-max utility (first maximum wins, algorithms.py:153-159) and penalty += 1 (:161) ----
-        if (wave == 0) {
-            double bu = 0.0; int bp = kNoKey;
-#pragma unroll
-            for (int q = 0; q < GP; ++q) {
-                const int p = lane + q * kWave;
-                if (p < n) {
-                    const double util = gq[q] / (1.0 + (double)pq[q]);
-                    if (bp == kNoKey || util > bu) { bu = util; bp = p; }
-                }
-            }
-            wave_argmax_first(bu, bp);
-            const int eu0 = t[bp], ev0 = t[bp + 1];
-            bool ovf = false;
-#pragma unroll
-            for (int q = 0; q < GP; ++q)
-                if (bp == lane + q * kWave) { ovf = s.pen_set(eu0, ev0, pq[q]); pq[q] += 1; }
-            int word = bp;
-            if (__ballot(ovf) != 0ull) word = -2;                              // counter overflow: stop this instance
-            if ((steps & 63) == 63 && wall_clock64() - t_start > (long long)(A.watchdog_s * 1e8)) word = -1;
-            if (lane == 0) ctl->flag = word;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the penalty store precedes the other waves' loads
-            STAMP_END(0);   // utility arg-max + penalty update
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int bp = ctl->flag;
-        if (bp < 0) { status = bp == -1 ? GNNGLS_STATUS_WATCHDOG_DEV : GNNGLS_STATUS_PENALTY_OVERFLOW_DEV; break; }
-        const int eu = t[bp], ev = t[bp + 1];
-        bool moved_this_step = false;
-        int i_cur = 0;                                                         // index of the endpoint whose scans are being consumed
-        int next = 0;                                                          // first scan (0..3 = side*2 + op) not yet consumed
-        while (next < 4) {
-            // ---- speculative round: wavefront w evaluates scan w (if it is still to be consumed) on the current tour ----
-            double bd = 0.0; int bk = kNoKey; int iw = 0;
-            if (wave < 4 && wave >= next) {
-                const int side = wave >> 1, node = side == 0 ? eu : ev;
-                if (node != 0) {                                               // algorithms.py:168
-                    if ((next & 1) == 1 && side == (next >> 1)) iw = i_cur;    // second scan of the endpoint in progress: stale index
-                    else if (!moved_this_step) iw = bp + side;                 // the edge was read at positions bp, bp+1
-                    else {
-                        for (int p0 = 0; p0 <= n; p0 += kWave) {               // algorithms.py:169 cur_tour.index(n)
-                            const int p = p0 + lane;
-                            const unsigned long long m = __ballot(p <= n && t[p] == node);
-                            if (m) { iw = p0 + __ffsll((long long)m) - 1; break; }
-                        }
-                    }
-                    if ((wave & 1) == 0) scan_two_opt_o2a_guided<S, FI>(s, k, t, n, iw, lane, bd, bk);
-                    else                 scan_relocate_o2a_guided<S, FI>(s, k, t, n, iw, lane, bd, bk);
-                    if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
-                }
-                if (lane == 0) { ctl->red_d[phase][wave] = bd; ctl->red_k[phase][wave] = bk; ctl->red_k[phase][4 + wave] = iw; }
-            }
-            if (wave == 0) STAMP_END(1);   // scan round (wavefront 0's view)
-            __syncthreads();
-            // ---- consume the results in the reference's order (every wavefront takes the same decisions) ----
-            int s_move = -1;
-            for (int sc = next; sc < 4; ++sc) {
-                const int node = (sc >> 1) == 0 ? eu : ev;
-                if (node == 0) continue;
-                if (tid == 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
-                if ((sc & 1) == 0) i_cur = ctl->red_k[phase][4 + sc];          // first scan of an endpoint fixes its index
-                if (ctl->red_k[phase][sc] != kNoKey) { s_move = sc; break; }
-            }
-            const int mj = s_move >= 0 ? ctl->red_k[phase][s_move] : 0;
-            const int mi = s_move >= 0 ? ctl->red_k[phase][4 + s_move] : 0;
-            phase ^= 1;
-            if (wave == 0) STAMP_END(2);   // barrier + decision
-            if (s_move < 0) break;
-            apply_move(s, t, t2, Ef, Eb, n, s_move & 1, mi, mj, tid, nthr, TR);   // algorithms.py:175
-            { TT *x = t; t = t2; t2 = x; }
-            __syncthreads();
-            any_moved = true;
-            moved_this_step = true;
-            moves += 1;                                                        // algorithms.py:185
-            if (wave == 0) {
-                reload_guides();
-                if (TR) {
-                    cur_cost = tour_cost_from_edges(Ef, n);                    // algorithms.py:176
-                    if (lane == 0) tr.push(cur_cost);
-                } else if (lane == 0) {
-                    tr.len++;                                                  // move counted, cost deferred
-                }
-                STAMP_END(3);   // apply move + reload
-            }
-            next = s_move + 1;
-        }
-        steps++;
-        if (wave == 0) STAMP_COUNT(6);
-    }
-    if (wave == 0) __builtin_amdgcn_s_setprio(0);
-}
-
 // launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
 // CU at n=100 need <= 80 VGPRs), 4 for the global-memory fallback.
-template <class S, bool FI, int GP, bool TR>
-__global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
+// WPS = resident wavefronts per SIMD the kernel is compiled for = its register budget (512 / WPS VGPRs).  The compact store
+// exists twice: WPS 4 (128 VGPRs, no spills: the instantiation a full TSP100 device load runs on, four 4-wave workgroups
+// per CU) and WPS 8 (64 VGPRs, ~100 B of scratch) for batches of small instances that need more than 16 waves per CU.
+template <class S, bool FI, int GP, bool TR, int WPS>
+__global__ __launch_bounds__(512, WPS) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int n = A.n;
@@ -1320,32 +996,13 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
         if (!ctl->flag) break;
         const double *guide = A.guides + ((size_t)(iter_i % A.n_guides) * A.B + b) * nn;   // algorithms.py:147
 
-        // ---- perturbation (algorithms.py:150-185) ----
-        bool par_moved = false;
-        const bool parallel_perturb = GLS_PARALLEL_PERTURB && S::kSymmetric && (nthr >> 6) >= 4;
-        if (parallel_perturb) {      // four wavefronts evaluate the four one-to-all scans of a step speculatively
-            STAMP_BEGIN();
-            perturb_parallel<S, FI, GP, TR>(s, A, guide, k, t, t2, Ef, Eb, n, ctl, phase, t_start, tr, evals, status, cur_cost,
-                                            par_moved, st);
-        }
-        if (wave == 0 && parallel_perturb) {
-            if (par_moved && !eager_cost) {
-                build_edges(s, t, Ef, Eb, n, lane, kWave);
-                wave_sync();
-                cur_cost = tour_cost_from_edges(Ef, n);
-            }
-            if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
-            STAMP_END(4);       // phase tail
-        }
-        if (wave == 0 && !parallel_perturb) {     // wavefront 0 only (small workgroups, global-memory store)
+        // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
+        if (wave == 0) {
             STAMP_BEGIN();
             // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
             // waves of the other resident workgroups on the same SIMD: give it priority while it runs
             __builtin_amdgcn_s_setprio(3);
             bool any_moved = false;
-            if constexpr (S::kSymmetric && GLS_FUSED_PERTURB) {
-                perturb_fused<S, FI, GP, TR>(s, A, guide, k, t, t2, Ef, Eb, n, lane, t_start, tr, evals, status, cur_cost, any_moved, st);
-            } else {
             int moves = 0;
             long long steps = 0;
             // utility numerators of the current tour edges, G.edges[e][guide] (algorithms.py:155), cached in
@@ -1447,7 +1104,6 @@ __global__ __launch_bounds__(512, S::kWavesPerSimd) void gls_kernel(GlsArgs A) {
                     if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
                 }
             }
-            }   // !kSymmetric
             if (any_moved && !eager_cost) {
                 build_edges(s, t, Ef, Eb, n, lane, kWave);
                 wave_sync();
@@ -1625,18 +1281,28 @@ int gls_block_threads(int n, int store) {
     if (n <= 24) return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
-    // compact store, 4 workgroups per CU, measured at TSP100 x 1024 (outer iterations per instance in 2 s):
-    //   8 waves, 64 VGPRs (32 B of scratch in the serial phase)            7.9k   <- used
-    //   4 waves, 128 VGPRs, no spills, descent scans batched 4-deep for ILP  7.4k
-    //   6 or 7 waves: a 2+2+1+1 wave split does not pack four workgroups on the 4 SIMDs (3 resident only)
-    //   5 waves at <= 80 VGPRs (no spills) pack and reach 9.6k vs 9.9k for 8 waves; at 85+ VGPRs they no longer pack
-    if (store == GLS_STORE_COMPACT) return GLS_COMPACT_THREADS;
+    // compact store with the lean descent scans (n <= 127), four workgroups per CU, measured at TSP100 x 1024 (outer
+    // iterations per instance in 2 s, weight / noise guide): 8 waves at 64 VGPRs (108 B of scratch) 11.6k / 7.0k;
+    // 4 waves at 128 VGPRs (no scratch) 12.3k / 7.5k  <- used.  (One workgroup alone on a CU prefers 8 waves, 16.1k vs
+    // 14.8k, but such small batches run on the LDS-penalty store anyway.)
+    if (store == GLS_STORE_COMPACT && n <= 2 * kWave - 1) return 256;
     return 512;
 }
 
-template <class S, bool FI, int GP, bool TR>
+int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, size_t lds) {
+    if (store == GLS_STORE_TRI) return TriStore<int32_t>::kWavesPerSimd;
+    if (store == GLS_STORE_GLOBAL) return GlobalStore::kWavesPerSimd;
+    // compact store: the 128-VGPR build unless the batch only fits with 8 waves per SIMD
+    const int waves = threads / kWave;
+    const int by_lds = (int)((160 * 1024) / lds);
+    const int per_cu4 = by_lds < 16 / waves ? by_lds : 16 / waves;
+    (void)n;
+    return (batch > 0 && (long)per_cu4 * num_cus < batch && 32 / waves > per_cu4 && by_lds > per_cu4) ? 8 : 4;
+}
+
+template <class S, bool FI, int GP, bool TR, int WPS>
 static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    auto kern = gls_kernel<S, FI, GP, TR>;
+    auto kern = gls_kernel<S, FI, GP, TR, WPS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1645,34 +1311,37 @@ static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStr
     return hipGetLastError();
 }
 
-template <class S, bool FI, int GP>
+template <class S, bool FI, int GP, int WPS>
 static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
     // trace_cap == 0 (no trace buffer): the trace-free instantiation (fewer live registers in the serial phase)
-    if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true>(A, lds, threads, stream);
-    return launch_gls_k<S, FI, GP, false>(A, lds, threads, stream);
+    if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true, WPS>(A, lds, threads, stream);
+    return launch_gls_k<S, FI, GP, false, WPS>(A, lds, threads, stream);
 }
 
-template <class S, bool FI>
+template <class S, bool FI, int WPS>
 static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover n <= 128
-    if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2>(A, lds, threads, stream);
-    return launch_gls_g<S, FI, kGuidePassesMax>(A, lds, threads, stream);
+    // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover positions 0..n for n <= 127
+    if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2, WPS>(A, lds, threads, stream);
+    return launch_gls_g<S, FI, kGuidePassesMax, WPS>(A, lds, threads, stream);
 }
 
-hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, bool first_improvement,
+template <class S, int WPS>
+static hipError_t launch_gls_f(const GlsArgs &A, size_t lds, int threads, bool first_improvement, hipStream_t stream) {
+    return first_improvement ? launch_gls_t<S, true, WPS>(A, lds, threads, stream)
+                             : launch_gls_t<S, false, WPS>(A, lds, threads, stream);
+}
+
+hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool first_improvement,
                       hipStream_t stream) {
     size_t lds = gls_lds_bytes(A.n, store, penalty_bits);
     if (store == GLS_STORE_COMPACT)
-        return first_improvement ? launch_gls_t<TriDGlobalP, true>(A, lds, threads, stream)
-                                 : launch_gls_t<TriDGlobalP, false>(A, lds, threads, stream);
+        return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)
+                        : launch_gls_f<TriDGlobalP, 4>(A, lds, threads, first_improvement, stream);
     if (store == GLS_STORE_TRI && penalty_bits == 16)
-        return first_improvement ? launch_gls_t<TriStore<uint16_t>, true>(A, lds, threads, stream)
-                                 : launch_gls_t<TriStore<uint16_t>, false>(A, lds, threads, stream);
+        return launch_gls_f<TriStore<uint16_t>, TriStore<uint16_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     if (store == GLS_STORE_TRI)
-        return first_improvement ? launch_gls_t<TriStore<int32_t>, true>(A, lds, threads, stream)
-                                 : launch_gls_t<TriStore<int32_t>, false>(A, lds, threads, stream);
-    return first_improvement ? launch_gls_t<GlobalStore, true>(A, lds, threads, stream)
-                             : launch_gls_t<GlobalStore, false>(A, lds, threads, stream);
+        return launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+    return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
 }
 
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream) {

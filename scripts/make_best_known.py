@@ -75,7 +75,8 @@ def main():
                         "new_best": int(better.sum())})
             print(json.dumps(log[-1]), flush=True)
         if k == 0 and args.oracle_instances != 0:
-            m = min(args.oracle_instances if args.oracle_instances > 0 else (os.cpu_count() or 1), args.count)
+            m = min(args.oracle_instances if args.oracle_instances > 0 else (os.cpu_count() or 1), args.count)   # NB: beyond the
+            # container's CPU quota the workers only time-slice (the committed TSP100 file: 256 workers on 16 CPUs)
             init = ops.nearest_neighbor(D[:m].contiguous())
             init_cost = ops.tour_cost(init, D[:m].contiguous())
             with tempfile.TemporaryDirectory() as td:

@@ -53,7 +53,7 @@ def test_bench_strong_scaling_two_ranks_gloo():
     env = dict(os.environ, GNNGLS_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--n", "20", "--total_instances", "151", "--time_limit", "0.4", "--guides", "weight", "--resident_instances", "32"]
+           "--tsp_n", "20", "--total_instances", "151", "--time_limit", "0.4", "--guides", "weight", "--resident_instances", "32"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.STDOUT, timeout=600)
     j = last_json_line(out)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_instances"] == 151

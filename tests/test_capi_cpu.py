@@ -86,10 +86,14 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_gls_store_selection(lib):
-    """Fastest store that keeps the batch resident; the compact store is exactly 40 KiB at n=100 (4 per CU)."""
+    """Fastest store that keeps the batch resident; the compact store is exactly 40 KiB at n=100 (4 per CU, four
+    4-wave workgroups on the 128-VGPR build)."""
     from gnngls_amd import ops
     c = ops.gls_describe_config(100, 1024)
-    assert c == {"store": "compact", "threads": 512, "lds_bytes": 40960, "per_cu": 4}
+    assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4}
+    assert ops.gls_resident_capacity(100) == 1024 and ops.gls_resident_capacity(50) == 2048
+    assert ops.gls_describe_config(50, 1024)["per_cu"] >= 4 and ops.gls_describe_config(50, 2048)["per_cu"] == 8
+    assert ops.gls_describe_config(20, 1000)["threads"] == 64 and ops.gls_describe_config(20, 1000)["per_cu"] >= 4
     assert ops.gls_describe_config(100, 512)["store"] == "lds-tri-i32" and ops.gls_describe_config(100, 512)["per_cu"] == 2
     assert ops.gls_describe_config(100, 513)["store"] == "compact"            # 16-bit LDS counters only on request
     assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3}
