@@ -564,8 +564,8 @@ int gnngls_debug_set_penalty16_limit(int limit) {
 }
 
 int gnngls_debug_set_gls_threads(int threads) {
-    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512)
-        return fail(GNNGLS_ERR_ARG, "gls threads override must be 0 (default policy), 64, 128, 256 or 512");
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
+        return fail(GNNGLS_ERR_ARG, "gls threads override must be 0 (default policy), 64, 128, 256, 512 or 1024");
     gnngls::gls_set_block_threads_override(threads);
     return GNNGLS_OK;
 }

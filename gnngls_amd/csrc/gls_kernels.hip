@@ -348,7 +348,17 @@ __device__ __forceinline__ void block_reduce_best(Ctl *ctl, int &phase, int wave
                                                   double &d, int &k) {
     wave_reduce_best<FI>(d, k);
     if (nwaves == 1) return;
-    if (lane == 0) { ctl->red_d[phase][wave] = d; ctl->red_k[phase][wave] = k; }
+    if (nwaves > 8) {        // 9..16 wavefronts: the upper ones hand their result to wavefront w - 8 first (8 exchange slots)
+        if (wave >= 8 && lane == 0) { ctl->red_d[phase][wave - 8] = d; ctl->red_k[phase][wave - 8] = k; }
+        __syncthreads();
+        if (wave + 8 < nwaves) {
+            const double od = ctl->red_d[phase][wave]; const int ok = ctl->red_k[phase][wave];
+            if (better<FI>(od, ok, d, k)) { d = od; k = ok; }
+        }
+        phase ^= 1;
+        nwaves = 8;
+    }
+    if (lane == 0 && wave < 8) { ctl->red_d[phase][wave] = d; ctl->red_k[phase][wave] = k; }
     __syncthreads();
     d = ctl->red_d[phase][0]; k = ctl->red_k[phase][0];
     for (int w = 1; w < nwaves; ++w) {
@@ -562,16 +572,20 @@ __device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *
 //   * within a lane the keys (i, j) ascend, so "first minimum wins" is a plain strict `delta < best` (no key compare);
 //     np.isclose is only evaluated for a candidate that already beats the lane's best.
 // Same deltas (same operand order), same keys, same arg-min as the scans above.
-struct LaneTour {      // positions lane and lane + 64 of the tour (and of Ef) in registers
-    int t0, t1;
-    double e0, e1;
+template <int SL>
+struct LaneTour {      // positions lane, lane + 64, ... (SL slots) of the tour and of Ef in registers
+    int t[SL];
+    double e[SL];
 };
-template <class TT>
-__device__ __forceinline__ LaneTour load_lane_tour(const TT *t, const double *Ef, int n, int lane) {
-    LaneTour L;
-    const int p1 = lane + kWave <= n ? lane + kWave : n;
-    L.t0 = t[lane <= n ? lane : n]; L.t1 = t[p1];
-    L.e0 = Ef[lane <= n ? lane : n]; L.e1 = Ef[p1];          // Ef[0] is never used
+template <int SL, class TT>
+__device__ __forceinline__ LaneTour<SL> load_lane_tour(const TT *t, const double *Ef, int n, int lane) {
+    LaneTour<SL> L;
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        const int p = lane + q * kWave <= n ? lane + q * kWave : n;
+        L.t[q] = t[p];
+        L.e[q] = Ef[p];                                      // Ef[0] is never used
+    }
     return L;
 }
 __device__ __forceinline__ int bcast_int(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
@@ -580,9 +594,14 @@ __device__ __forceinline__ double bcast_f64(double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane((int)b, src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-// position p (wave-uniform) -> tour node / edge length, from the lane-resident copies
-#define LT_NODE(L, p) ((p) < kWave ? bcast_int((L).t0, (p)) : bcast_int((L).t1, (p) - kWave))
-#define LT_EDGE(L, p) ((p) < kWave ? bcast_f64((L).e0, (p)) : bcast_f64((L).e1, (p) - kWave))
+// position p (wave-uniform) -> tour node, from the lane-resident copies (v_readlane takes the lane index modulo 64)
+template <int SL>
+__device__ __forceinline__ int lane_tour_node(const LaneTour<SL> &L, int p) {
+    int r = bcast_int(L.t[0], p);
+#pragma unroll
+    for (int q = 1; q < SL; ++q) if (p >= q * kWave) r = bcast_int(L.t[q], p);
+    return r;
+}
 
 // split [lo, hi) over `parts` consecutive chunks; chunk `c` -> [*a, *b)
 __device__ __forceinline__ void chunk_range(int lo, int hi, int parts, int c, int &a, int &b) {
@@ -592,15 +611,31 @@ __device__ __forceinline__ void chunk_range(int lo, int hi, int parts, int c, in
     if (b > hi) b = hi;
 }
 
-template <class S, class TT>
+// `nwaves` wavefronts over R row blocks in proportion to the blocks' work len[0..R): wave -> (rb, part, parts).
+// Every block gets at least one wavefront (callers guarantee nwaves >= R); all values are wave-uniform.
+__device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, int wave, int &rb, int &part, int &parts) {
+    int total = 0;
+    for (int r = 0; r < R; ++r) total += len[r];
+    int cnt[4], given = 0;
+    for (int r = 0; r < R; ++r) { cnt[r] = 1 + (int)((long)(nwaves - R) * len[r] / (total > 0 ? total : 1)); given += cnt[r]; }
+    for (int r = 0; given < nwaves; r = (r + 1) % R) { cnt[r] += 1; given += 1; }      // leftovers: heaviest (first) blocks first
+    int first = 0;
+    rb = R - 1; part = 0; parts = cnt[R - 1];
+    for (int r = 0; r < R; ++r) {
+        if (wave < first + cnt[r]) { rb = r; part = wave - first; parts = cnt[r]; break; }
+        first += cnt[r];
+    }
+}
+
+template <int SL, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, const double *Ef, int n,
                                                        int wave, int nwaves, int lane, double &bd, int &bk) {
-    const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows (1 or 2)
+    const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows
     const int per_rb = nwaves / RW;                          // waves sharing a row block, each a contiguous k range
     const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
     const int part = __builtin_amdgcn_readfirstlane(wave - rb * per_rb);
-    if (per_rb == 0 || rb >= RW) return;                     // (nwaves >= RW always holds for the launch shapes used)
-    const LaneTour L = load_lane_tour(t, Ef, n, lane);
+    if (per_rb == 0 || rb >= RW) return;                     // callers guarantee nwaves >= RW; surplus waves idle
+    const LaneTour<SL> L = load_lane_tour<SL>(t, Ef, n, lane);
     const int i = 1 + rb * kWave + lane;
     const bool row_ok = i <= n - 1;                          // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
     const int ic = row_ok ? i : 1;
@@ -612,11 +647,11 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     int k0, k1;
     chunk_range(0, n, per_rb, part, k0, k1);                 // target edges k = 0 .. n-1
     if (k0 >= k1) return;
-    int d = LT_NODE(L, k0);
-    double vd = s.dist_at(s.idx2(b, b2, d, (d * (d - 1)) >> 1));          // D[t[k0], b]   (garbage, unused, where t[k0] == b)
+    const int d0 = lane_tour_node(L, k0);
+    double vd = s.dist_at(s.idx2(b, b2, d0, (d0 * (d0 - 1)) >> 1));       // D[t[k0], b]   (garbage, unused, where t[k0] == b)
     // U steps at a time: all wave-uniform operands, indices and the U random distance reads are issued before the first
     // dependent add, so the LDS round trips of a group overlap (a step alone is a ~280-cycle dependent chain)
-    auto group = [&](int k, int te, double ee, auto ucount) {
+    auto group = [&](int k, int te, double ee, auto ucount) {     // te / ee: the register slot holding positions k+1 .. k+U
         constexpr int U = decltype(ucount)::value;
         double ve[U], de[U];
 #pragma unroll
@@ -639,34 +674,31 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             }
         }
     };
-    using U4 = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
     using U1 = std::integral_constant<int, 1>;
-    const int ksplit = kWave - 1;                            // position k + 1 <= 63  <=>  k < 63
-    const int ka = k1 < ksplit ? k1 : ksplit;                // slot 0: k in [k0, ka)
-    int k = k0;
-    for (; k + GLS_LEAN_UNROLL <= ka; k += GLS_LEAN_UNROLL) group(k, L.t0, L.e0, U4{});
-    for (; k < ka; ++k) group(k, L.t0, L.e0, U1{});
-    k = k0 > ksplit ? k0 : ksplit;                           // slot 1: k in [max(k0, 63), k1)
-    for (; k + GLS_LEAN_UNROLL <= k1; k += GLS_LEAN_UNROLL) group(k, L.t1, L.e1, U4{});
-    for (; k < k1; ++k) group(k, L.t1, L.e1, U1{});
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {                           // slot q holds positions 64q .. 64q+63, i.e. k + 1 of k in [64q-1, 64q+62]
+        const int lo = q * kWave - 1, hi = q * kWave + kWave - 1;
+        int k = k0 > lo ? k0 : lo;
+        const int ke = k1 < hi ? k1 : hi;
+        for (; k + GLS_LEAN_UNROLL <= ke; k += GLS_LEAN_UNROLL) group(k, L.t[q], L.e[q], UN{});
+        for (; k < ke; ++k) group(k, L.t[q], L.e[q], U1{});
+    }
 }
 
-template <class S, class TT>
+template <int SL, class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, const double *Eb, int n,
                                                       int wave, int nwaves, int lane, double &bd, int &bk) {
     // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39): rows i = 1..n-3, j = i+2..n-1.  Row block rb can use
-    // j >= 3 + 64 rb: block 0 has ~3x the work of block 1, so the waves are shared out in proportion to the j ranges.
+    // j >= 3 + 64 rb: the first block has the most work, so the waves are shared out in proportion to the j ranges.
     const int RW = (n - 3 + kWave - 1) / kWave;              // row blocks with at least one valid row
     if (RW <= 0) return;
-    const int len0 = n - 3, len1 = RW > 1 ? n - 3 - kWave : 0;   // number of j values block 0 / block 1 walks
-    int w1 = RW > 1 ? (nwaves * len1 + (len0 + len1) / 2) / (len0 + len1) : 0;
-    if (RW > 1 && w1 < 1) w1 = 1;
-    if (w1 > nwaves - 1) w1 = nwaves - 1;
-    const int w0 = nwaves - w1;
-    const int rb = __builtin_amdgcn_readfirstlane(wave < w0 ? 0 : 1);
-    const int part = __builtin_amdgcn_readfirstlane(wave < w0 ? wave : wave - w0);
-    const int parts = rb == 0 ? w0 : w1;
-    const LaneTour L = load_lane_tour(t, Eb, n, lane);
+    int len[4] = {0, 0, 0, 0};
+    for (int r = 0; r < RW && r < 4; ++r) len[r] = n - 3 - r * kWave;        // number of j values block r walks
+    int rb, part, parts;
+    assign_waves(len, RW, nwaves, wave, rb, part, parts);
+    rb = __builtin_amdgcn_readfirstlane(rb); part = __builtin_amdgcn_readfirstlane(part); parts = __builtin_amdgcn_readfirstlane(parts);
+    const LaneTour<SL> L = load_lane_tour<SL>(t, Eb, n, lane);
     const int i = 1 + rb * kWave + lane;
     const bool row_ok = i <= n - 3;
     const int ic = row_ok ? i : 1;
@@ -676,7 +708,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     int j0, j1;
     chunk_range(3 + rb * kWave, n, parts, part, j0, j1);     // j = j0 .. j1-1
     if (j0 >= j1) return;
-    int d = LT_NODE(L, j0 - 1);
+    int d = lane_tour_node(L, j0 - 1);
     int d2 = (d * (d - 1)) >> 1;
     auto group = [&](int j, int tj, double ej, auto ucount) {     // tj / ej: the register slot holding positions j .. j+U-1
         constexpr int U = decltype(ucount)::value;
@@ -700,15 +732,15 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             }
         }
     };
-    using U4 = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
     using U1 = std::integral_constant<int, 1>;
-    const int ja = j1 < kWave ? j1 : kWave;                  // slot 0: j in [j0, ja)
-    int j = j0;
-    for (; j + GLS_LEAN_UNROLL <= ja; j += GLS_LEAN_UNROLL) group(j, L.t0, L.e0, U4{});
-    for (; j < ja; ++j) group(j, L.t0, L.e0, U1{});
-    j = j0 > kWave ? j0 : kWave;                             // slot 1: j in [max(j0, 64), j1)
-    for (; j + GLS_LEAN_UNROLL <= j1; j += GLS_LEAN_UNROLL) group(j, L.t1, L.e1, U4{});
-    for (; j < j1; ++j) group(j, L.t1, L.e1, U1{});
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {                           // slot q holds positions j in [64q, 64q+63]
+        int j = j0 > q * kWave ? j0 : q * kWave;
+        const int je = j1 < (q + 1) * kWave ? j1 : (q + 1) * kWave;
+        for (; j + GLS_LEAN_UNROLL <= je; j += GLS_LEAN_UNROLL) group(j, L.t[q], L.e[q], UN{});
+        for (; j < je; ++j) group(j, L.t[q], L.e[q], U1{});
+    }
 }
 
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
@@ -837,7 +869,7 @@ struct Trace<false> {
     __device__ __forceinline__ void push(double) { len++; }
 };
 
-template <class S, bool FI, class TT, class TRC>
+template <class S, bool FI, int GP, class TT, class TRC>
 __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st) {
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -854,10 +886,12 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
             // software-pipelining the uniform operands one step ahead costs registers: 9.6k at TSP100
             if constexpr (!FI && S::kSymmetric) {
-                // positions 0..n fit two register slots per lane; every block of 64 rows needs a wavefront of its own
-                if (n <= 2 * kWave - 1 && nwaves >= (n - 1 + kWave - 1) / kWave) {
-                    if (op == 0) scan_two_opt_a2a_lean<S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
-                    else         scan_relocate_a2a_lean<S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+                // positions 0..n fit 2 (n <= 127) or 4 (n <= 255) register slots per lane; every block of 64 rows needs
+                // a wavefront of its own
+                // (GP = register slots of the perturbation phase = the same 2 / 4, chosen by the launcher from n)
+                if (nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
+                    if (op == 0) scan_two_opt_a2a_lean<GP, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                    else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
                     lean = true;
                 }
             }
@@ -893,7 +927,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 // exists twice: WPS 4 (128 VGPRs, no spills: the instantiation a full TSP100 device load runs on, four 4-wave workgroups
 // per CU) and WPS 8 (64 VGPRs, ~100 B of scratch) for batches of small instances that need more than 16 waves per CU.
 template <class S, bool FI, int GP, bool TR, int WPS>
-__global__ __launch_bounds__(512, WPS) void gls_kernel(GlsArgs A) {
+__global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int n = A.n;
@@ -973,7 +1007,7 @@ __global__ __launch_bounds__(512, WPS) void gls_kernel(GlsArgs A) {
     if (tid == 0 && A.imp_len) A.imp_len[b] = 0;
 
     STAMP_BEGIN();
-    local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);   // algorithms.py:142
+    local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
@@ -1123,7 +1157,7 @@ __global__ __launch_bounds__(512, WPS) void gls_kernel(GlsArgs A) {
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);
+        local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -1286,6 +1320,10 @@ int gls_block_threads(int n, int store) {
     // 4 waves at 128 VGPRs (no scratch) 12.3k / 7.5k  <- used.  (One workgroup alone on a CU prefers 8 waves, 16.1k vs
     // 14.8k, but such small batches run on the LDS-penalty store anyway.)
     if (store == GLS_STORE_COMPACT && n <= 2 * kWave - 1) return 256;
+    // compact store with ONE workgroup per CU (distance triangle > 80 KB, n >= 144; TSP200): the descent is latency-bound
+    // at two waves per SIMD -- 16 waves share the scans (measured TSP200 x 256, noise guide, iterations in 2 s: 8 waves
+    // 4.7k, 16 waves see profiles/)
+    if (store == GLS_STORE_COMPACT && 2 * gls_lds_bytes(n, GLS_STORE_COMPACT, 32) > 160 * 1024) return 1024;
     return 512;
 }
 
