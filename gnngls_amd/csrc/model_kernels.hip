@@ -243,25 +243,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 //   written to side (i<j ? 0 : 1) of the partial buffers; the other endpoint's row supplies the
 //   second half of the 2(n-2) in-neighbours.
 // ---------------------------------------------------------------------------------------------
-constexpr int LDF = kD + 16;   // LDS row stride of the staged ft tile (floats): the 4 source rows an MFMA
-                               // B-fragment read touches land on 4 disjoint groups of 16 banks
-
+// HS = heads per workgroup.  HS = 8: one workgroup stages the whole ft rows of TSP row i (n = 100: 57 KB of LDS, two
+// workgroups per CU).  HS = 4: the heads are split over two workgroups (columns [64 hg, 64 hg + 64) of the same rows):
+// the same arithmetic per head; used for n > 140 where the unsplit tile (n = 200: 115 KB) leaves one workgroup per CU
+// and nothing overlaps its prologue (staging, logits, top-2, factor tables: ~40 % of a workgroup's cycles).
+// LDS row stride of the staged ft tile (floats) = 16 HS + 16 = 16 (mod 64): the 4 source rows an MFMA B-fragment read
+// touches land on 4 disjoint groups of 16 banks.
+template <int HS>
 __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__ ft, const float *__restrict__ attn_l,
                                                        const float *__restrict__ attn_r, int n,
                                                        float *__restrict__ part, float *__restrict__ part_ms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LDF = HS * kF + 16;
+    constexpr int HG = kH / HS;                                  // workgroups per (instance, row)
     const int N = n * (n - 1) / 2;
     const int ns = n - 1;
-    const int b = blockIdx.x / n, i = blockIdx.x % n;
+    const int hb = (blockIdx.x % HG) * HS;                       // first head of this workgroup
+    const int b = blockIdx.x / (n * HG), i = (blockIdx.x / HG) % n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 4..8 waves, chosen by the launcher to balance the units
     float *ftS = reinterpret_cast<float *>(smem);            // [ns][LDF]
-    float *elS = ftS + (size_t)ns * LDF;                     // [ns][8]
-    float *erS = elS + (size_t)ns * kH;                      // [ns][8]
-    float *eaS = erS + (size_t)ns * kH;                      // [ns][8] exp(el - max1)            } factorised softmax weights,
-    float *ebS = eaS + (size_t)ns * kH;                      // [ns][8] exp(0.2 (el - max1))      } see the aggregation loop
-    float *top = ebS + (size_t)ns * kH;                      // [8][4]: max1, max2, argmax1 (int bits), direct-path flag
-    int *nodeS = reinterpret_cast<int *>(top + kH * 4);      // [ns] global node id of slot
+    float *elS = ftS + (size_t)ns * LDF;                     // [ns][HS]
+    float *erS = elS + (size_t)ns * HS;                      // [ns][HS]
+    float *eaS = erS + (size_t)ns * HS;                      // [ns][HS] exp(el - max1)            } factorised softmax weights,
+    float *ebS = eaS + (size_t)ns * HS;                      // [ns][HS] exp(0.2 (el - max1))      } see the aggregation loop
+    float *top = ebS + (size_t)ns * HS;                      // [HS][4]: max1, max2, argmax1 (int bits), direct-path flag
+    int *nodeS = reinterpret_cast<int *>(top + HS * 4);      // [ns] global node id of slot
 
     const float *ftb = ft + (size_t)b * N * kD;
     for (int s = tid; s < ns; s += nthreads) {
@@ -269,34 +276,35 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
         nodeS[s] = k < i ? pair_index(k, i, n) : pair_index(i, k, n);
     }
     __syncthreads();
-    // stage ft rows: 32 x 16 B per node, coalesced; the loads of a batch are all issued before the first LDS store (a
-    // thread moves ~7 float4 at n = 100: one global round trip instead of seven)
+    // stage the workgroup's head columns of the ft rows: 4 HS x 16 B per node, coalesced; the loads of a batch are all
+    // issued before the first LDS store (a thread moves ~7 float4 at n = 100: one global round trip instead of seven)
     constexpr int SB = 8;
-    for (int q0 = tid; q0 < ns * (kD / 4); q0 += nthreads * SB) {
+    constexpr int V4 = HS * kF / 4;                              // float4 per staged row
+    for (int q0 = tid; q0 < ns * V4; q0 += nthreads * SB) {
         f32x4 v[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int q = q0 + u * nthreads;
-            if (q < ns * (kD / 4)) v[u] = *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[q >> 5] * kD + (q & 31) * 4);
+            if (q < ns * V4) v[u] = *reinterpret_cast<const f32x4 *>(ftb + (size_t)nodeS[q / V4] * kD + hb * kF + (q % V4) * 4);
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int q = q0 + u * nthreads;
-            if (q < ns * (kD / 4)) *reinterpret_cast<f32x4 *>(ftS + (size_t)(q >> 5) * LDF + (q & 31) * 4) = v[u];
+            if (q < ns * V4) *reinterpret_cast<f32x4 *>(ftS + (size_t)(q / V4) * LDF + (q % V4) * 4) = v[u];
         }
     }
     __syncthreads();
-    {   // el / er (GATConv: (feat * attn).sum(-1)); the head of a thread is fixed (the stride is a multiple of 8): its
+    {   // el / er (GATConv: (feat * attn).sum(-1)); the head of a thread is fixed (the stride is a multiple of HS): its
         // attention vectors live in registers, the ft slice comes in as four ds_read_b128
-        const int h = tid & 7;
+        const int h = tid % HS;
         f32x4 al[4], ar[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            al[v] = *reinterpret_cast<const f32x4 *>(attn_l + h * kF + 4 * v);
-            ar[v] = *reinterpret_cast<const f32x4 *>(attn_r + h * kF + 4 * v);
+            al[v] = *reinterpret_cast<const f32x4 *>(attn_l + (hb + h) * kF + 4 * v);
+            ar[v] = *reinterpret_cast<const f32x4 *>(attn_r + (hb + h) * kF + 4 * v);
         }
-        for (int q = tid; q < ns * kH; q += nthreads) {
-            const float *f = ftS + (size_t)(q >> 3) * LDF + h * kF;
+        for (int q = tid; q < ns * HS; q += nthreads) {
+            const float *f = ftS + (size_t)(q / HS) * LDF + h * kF;
             float l = 0.f, r = 0.f;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -308,11 +316,11 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
         }
     }
     __syncthreads();
-    if (tid < 256) {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles
+    if (tid < 32 * HS) {   // top-2 of el per head over the row's sources: 32 lanes per head, merge (max1, arg1, max2) by shuffles
         const int h = tid >> 5, l32 = tid & 31;
         float m1 = -INFINITY, m2 = -INFINITY; int a1 = -1;
         for (int s = l32; s < ns; s += 32) {
-            float v = elS[s * kH + h];
+            float v = elS[s * HS + h];
             if (v > m1) { m2 = m1; m1 = v; a1 = s; } else if (v > m2) { m2 = v; }
         }
 #pragma unroll
@@ -332,8 +340,8 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                         top[h * 4 + 3] = (m1 - m2 > 60.f) ? 1.f : 0.f; }
     }
     __syncthreads();
-    for (int q = tid; q < ns * kH; q += nthreads) {
-        const float d = (elS[q] - top[(q & 7) * 4]) * 1.4426950408889634f;
+    for (int q = tid; q < ns * HS; q += nthreads) {
+        const float d = (elS[q] - top[(q % HS) * 4]) * 1.4426950408889634f;
         eaS[q] = __builtin_amdgcn_exp2f(d);
         ebS[q] = __builtin_amdgcn_exp2f(kSlope * d);
     }
@@ -348,10 +356,10 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
     const int jl = lane & 15, kq = lane >> 4;
     float *pb = part + (size_t)b * N * kD;
     float *mb = part_ms + (size_t)b * N * (2 * kH);
-    const size_t side_stride = (size_t)gridDim.x / n * N;     // B*N nodes per side
+    const size_t side_stride = (size_t)gridDim.x / (n * HG) * N;     // B*N nodes per side
     constexpr int HU = 4;                                      // heads per unit (independent MFMA chains)
-    for (int unit = wave; unit < n_dt * (kH / HU); unit += nwaves) {
-        const int dt = unit / (kH / HU), h0 = (unit % (kH / HU)) * HU;
+    for (int unit = wave; unit < n_dt * (HS / HU); unit += nwaves) {
+        const int dt = unit / (HS / HU), h0 = (unit % (HS / HU)) * HU;      // h0: head index inside the workgroup's HS heads
         const int js = dt * 16 + jl;
         const int jsc = js < ns ? js : ns - 1;
         float er[HU], mm[HU], nm[HU], ws[HU], cpos[HU], cneg[HU], ner[HU];
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
 #pragma unroll
         for (int u = 0; u < HU; ++u) {
             const int h = h0 + u;
-            er[u] = erS[jsc * kH + h];
+            er[u] = erS[jsc * HS + h];
             float m = ((__float_as_int(top[h * 4 + 2]) == js) ? top[h * 4 + 1] : top[h * 4 + 0]) + er[u];
             mm[u] = m > 0.f ? m : kSlope * m;      // LeakyReLU is monotone: max score = score of max el
             nm[u] = -mm[u] * kLog2e;
@@ -387,9 +395,9 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                     const int s = s0 + 4 * g + kq;
                     sidx[g] = s < ns ? s : ns - 1;
                     live[g] = (s < ns) && (s != js);              // no self loop, no padding
-                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
-                    ea[g] = *reinterpret_cast<const f32x4 *>(eaS + sidx[g] * kH + h0);
-                    eb[g] = *reinterpret_cast<const f32x4 *>(ebS + sidx[g] * kH + h0);
+                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * HS + h0);
+                    ea[g] = *reinterpret_cast<const f32x4 *>(eaS + sidx[g] * HS + h0);
+                    eb[g] = *reinterpret_cast<const f32x4 *>(ebS + sidx[g] * HS + h0);
 #pragma unroll
                     for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
                 }
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                     const int s = s0 + 4 * g + kq;
                     sidx[g] = s < ns ? s : ns - 1;
                     live[g] = (s < ns) && (s != js);
-                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * kH + h0);
+                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * HS + h0);
 #pragma unroll
                     for (int u = 0; u < HU; ++u) bv[g][u] = ftS[(size_t)sidx[g] * LDF + (h0 + u) * kF + jl];
                 }
@@ -445,14 +453,14 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                 const size_t node = (size_t)nodeS[jd];
                 float *po = pb + (i < j ? 0 : side_stride * kD) + node * kD;
 #pragma unroll
-                for (int u = 0; u < HU; ++u) po[(h0 + u) * kF + jl] = acc[u][r];
+                for (int u = 0; u < HU; ++u) po[(hb + h0 + u) * kF + jl] = acc[u][r];
             }
         }
         if (kq == 0 && js < ns) {
             const int j = js < i ? js : js + 1;
             float *mo = mb + (i < j ? 0 : side_stride * (2 * kH)) + (size_t)nodeS[js] * (2 * kH);
 #pragma unroll
-            for (int u = 0; u < HU; ++u) { mo[h0 + u] = mm[u]; mo[kH + h0 + u] = ws[u]; }
+            for (int u = 0; u < HU; ++u) { mo[hb + h0 + u] = mm[u]; mo[kH + hb + h0 + u] = ws[u]; }
         }
     }
 }
@@ -720,10 +728,16 @@ static int grid_for(long total, int block, int cap = 256 * 16) {
     return (int)g;
 }
 
-size_t gat_rows_lds_bytes(int n) {
+static size_t gat_rows_lds_bytes_hs(int n, int hs) {
     size_t ns = (size_t)n - 1;
-    return ns * LDF * 4 + 4 * ns * kH * 4 + kH * 4 * 4 + ns * 4 + 16;
+    return ns * (size_t)(hs * kF + 16) * 4 + 4 * ns * hs * 4 + (size_t)hs * 4 * 4 + ns * 4 + 16;
 }
+// heads per workgroup: all 8 while at least two such workgroups fit a CU, else the head-split form (4).  Measured per
+// launch (profiles/r02_ab_gat_heads.log): TSP200 x 256 11.5 -> 8.5 ms with the split (one -> two workgroups per CU);
+// TSP100 x 1024 5.33 -> 5.69 ms, TSP50 x 2048 1.73 -> 1.82 ms (two+ workgroups already hide the prologue; the split
+// only adds workgroup starts), so it is used where the unsplit tile leaves a CU with a single workgroup.
+static int gat_rows_heads(int n) { return gat_rows_lds_bytes_hs(n, kH) * 2 <= (size_t)160 * 1024 ? kH : 4; }
+size_t gat_rows_lds_bytes(int n) { return gat_rows_lds_bytes_hs(n, gat_rows_heads(n)); }
 
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st) {
     long total = (long)B * (n * (n - 1) / 2);
@@ -773,26 +787,37 @@ hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M
     return hipGetLastError();
 }
 
-hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
-                           float *part_ms, hipStream_t st) {
-    size_t lds = gat_rows_lds_bytes(n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gat_rows_kernel),
+template <int HS>
+static hipError_t launch_gat_rows_hs(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
+                                     float *part_ms, hipStream_t st) {
+    const size_t lds = gat_rows_lds_bytes_hs(n, HS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gat_rows_kernel<HS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    // units = (16-destination tiles) x (2 head quads), spread over 4..8 waves: the wave count with the fewest idle wave
-    // slots; on ties the one that brings the CU closest to 16 resident waves at the LDS-limited workgroup count
-    const int units = ((n - 1 + 15) / 16) * 2;
+    // units = (16-destination tiles) x (head quads of the workgroup), spread over 4..8 waves: the wave count with the
+    // fewest idle wave slots; on ties the one that brings the CU closest to 16 resident waves at the LDS-limited
+    // workgroup count
+    const int units = ((n - 1 + 15) / 16) * (HS / 4);
     const int wgs_per_cu = (int)((size_t)160 * 1024 / lds) > 0 ? (int)((size_t)160 * 1024 / lds) : 1;
-    const int want = 16 / wgs_per_cu;
+    const int want = 16 / wgs_per_cu > 0 ? 16 / wgs_per_cu : 1;
     int waves = 4;
     for (int w = 5; w <= 8; ++w) {
         const int idle_w = (units + w - 1) / w * w - units, idle_b = (units + waves - 1) / waves * waves - units;
         const int dw = w > want ? w - want : want - w, db = waves > want ? waves - want : want - waves;
         if (idle_w < idle_b || (idle_w == idle_b && dw < db)) waves = w;
     }
-    hipLaunchKernelGGL(gat_rows_kernel, dim3((unsigned)(B * n)), dim3(64 * waves), lds, st, ft, attn_l, attn_r, n, part, part_ms);
+    hipLaunchKernelGGL(gat_rows_kernel<HS>, dim3((unsigned)(B * n * (kH / HS))), dim3(64 * waves), lds, st, ft, attn_l, attn_r,
+                       n, part, part_ms);
     return hipGetLastError();
+}
+
+hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *attn_r, int B, int n, float *part,
+                           float *part_ms, hipStream_t st) {
+    static const char *force = getenv("GNNGLS_GAT_HEADS");      // experiments: 8 or 4
+    const int hs = force ? atoi(force) : gat_rows_heads(n);
+    return hs == 4 ? launch_gat_rows_hs<4>(ft, attn_l, attn_r, B, n, part, part_ms, st)
+                   : launch_gat_rows_hs<kH>(ft, attn_l, attn_r, B, n, part, part_ms, st);
 }
 
 template <int MODE>
