@@ -34,7 +34,7 @@ def main():
     for ci in range(args.cases):
         c = dict(n=int(master.integers(args.min_n, args.max_n + 1)), kind=str(master.choice(["euclid", "lattice", "noisy"])),
                  pm=int(master.choice([1, 5, 20, 30])), fi=bool(master.integers(0, 2)), K=int(master.integers(1, args.max_k + 1)),
-                 bits=int(master.choice([0, 16, 32, -1])), guides=int(master.integers(1, 3)), seed=int(master.integers(1 << 30)))
+                 bits=int(master.choice([0, 16, 32, -1, -2])), guides=int(master.integers(1, 3)), seed=int(master.integers(1 << 30)))
         rng = np.random.default_rng(c["seed"])
         n, B = c["n"], 3
         Ds, Gs = zip(*[make_case(rng, n, c["kind"]) for _ in range(B)])

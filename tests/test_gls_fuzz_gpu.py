@@ -34,6 +34,14 @@ for _ in range(48):
                       bits=int(_rng.choice([0, 16, 32])), guides=int(_rng.integers(1, 3)), seed=int(_rng.integers(1 << 30))))
 
 
+# round 2: the 4-register-slot lean scans, 16-wave workgroups and the forced compact store (n = 128..255, bits -2)
+_rng2 = np.random.default_rng(24680)
+for _ in range(14):
+    CASES.append(dict(n=int(_rng2.integers(120, 256)), kind=str(_rng2.choice(["euclid", "lattice", "noisy"])),
+                      pm=int(_rng2.choice([5, 20])), fi=bool(_rng2.integers(0, 2)), K=int(_rng2.integers(1, 3)),
+                      bits=int(_rng2.choice([0, -2])), guides=int(_rng2.integers(1, 3)), seed=int(_rng2.integers(1 << 30))))
+
+
 @pytest.mark.parametrize("c", CASES, ids=lambda c: f"n{c['n']}-{c['kind']}-pm{c['pm']}-fi{int(c['fi'])}-K{c['K']}-b{c['bits']}-g{c['guides']}")
 def test_fuzz_case(c):
     from gnngls_amd import ops
