@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gnngls_hip.h"
@@ -30,9 +32,11 @@ int hip_fail(hipError_t e, const char *what) {
 }
 
 // ---- optional per-kernel-class timing with HIP events on the caller's stream -------------------
-// (measurement hook for bench.py: process-global and not thread-safe; off unless gnngls_profile_enable(1) was called)
+// (measurement hook for bench.py: process-global; the span log is guarded by a mutex so that concurrent callers on
+// different host threads / streams may log safely; off unless gnngls_profile_enable(1) was called)
 struct ProfSpan { int kind; hipEvent_t a, b; };
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mutex;
 std::vector<ProfSpan> g_spans;
 
 struct ProfScope {
@@ -43,7 +47,11 @@ struct ProfScope {
     ~ProfScope() {
         if (!a) return;
         hipEvent_t b;
-        if (hipEventCreate(&b) == hipSuccess) { (void)hipEventRecord(b, st); g_spans.push_back({kind, a, b}); }
+        if (hipEventCreate(&b) == hipSuccess) {
+            (void)hipEventRecord(b, st);
+            std::lock_guard<std::mutex> lock(g_prof_mutex);
+            g_spans.push_back({kind, a, b});
+        }
         else (void)hipEventDestroy(a);
     }
 };
@@ -576,6 +584,7 @@ int gnngls_debug_set_stamp_buffer(void *device_buffer) {
 }
 
 int gnngls_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (auto &sp : g_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     g_spans.clear();
     g_prof_on = on != 0;
@@ -585,7 +594,9 @@ int gnngls_profile_enable(int on) {
 int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind) {
     if (!ms_by_kind || !launches_by_kind) return fail(GNNGLS_ERR_ARG, "profile_collect: bad argument");
     for (int k = 0; k < GNNGLS_PROF_KINDS; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
-    for (auto &sp : g_spans) {
+    std::vector<ProfSpan> spans;
+    { std::lock_guard<std::mutex> lock(g_prof_mutex); spans.swap(g_spans); }
+    for (auto &sp : spans) {
         hipError_t e = hipEventSynchronize(sp.b);
         if (e != hipSuccess) return hip_fail(e, "profile_collect");
         float ms = 0.f;
@@ -594,7 +605,6 @@ int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind) {
         ms_by_kind[sp.kind] += ms; launches_by_kind[sp.kind] += 1;
         (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
     }
-    g_spans.clear();
     return GNNGLS_OK;
 }
 

@@ -124,6 +124,7 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
     local_search only), init_tour [B,n+1] int32, init_cost [B] fp64.
     penalty_bits: 0 = auto (see include/gnngls_hip.h).  With retry_overflow (default) instances whose
     16-bit penalty counters overflowed are rerun with 32-bit counters (needs a host sync).
+    (Such a rerun gets the same time_limit_s again: with penalty_bits=16 a wall-clock run can take twice the limit.)
     imp_cap > 0 records the improvement trace (bounded however long the run is; see include/gnngls_hip.h).
     watchdog_s: None = time_limit_s + 5 s in wall-clock mode; in iteration-count mode a bound that scales with the
     requested work (the caller asked for exactly that many iterations, so the watchdog only catches hangs)."""
