@@ -86,12 +86,26 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
         if (done) return;
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
-        const int threads = gnngls::gls_block_threads(n, store);
+        int threads = gnngls::gls_block_threads(n, store);
+        // compact store, batch larger than the 128-VGPR build keeps resident at the default workgroup size: halve the
+        // workgroup (down to the wavefronts the lean scans need, one per block of 64 rows) before falling back to the
+        // 64-VGPR build -- TSP50 x 2048 on 2-wave workgroups at 128 VGPRs: 6.2k outer iterations per second vs 5.6k on
+        // 4-wave workgroups at 64 VGPRs (profiles/r02_ab_small_n_threads.log)
+        if (store == gnngls::GLS_STORE_COMPACT && batch > 0) {
+            const int by_lds = (int)(kLdsPerCU / lds);
+            const int min_threads = 64 * ((n - 1 + 63) / 64);
+            while (threads > min_threads && threads > 64) {
+                const int per4 = by_lds < 16 / (threads / 64) ? by_lds : 16 / (threads / 64);
+                if ((long)per4 * cus >= batch || per4 == by_lds) break;
+                threads /= 2;
+            }
+        }
         // wave slots per CU at the register budget of the kernel instantiation: LDS-penalty stores 80 VGPRs -> 6 waves
         // per SIMD (24 per CU); compact store 128 VGPRs -> 4 per SIMD, or its 64-VGPR build -> 8 per SIMD when only that
         // keeps the batch resident (and, without a batch size, for the capacity query)
         int wps = gnngls::gls_waves_per_simd(store, n, batch, cus, threads, lds);
         if (store == gnngls::GLS_STORE_COMPACT && batch <= 0) wps = 8;
+        if (store == gnngls::GLS_STORE_TRI && bits == 16) wps = 6;            // the uint16 variant only exists as the 80-VGPR build
         const int by_waves = (wps * 4) / (threads / 64);
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;

@@ -40,6 +40,9 @@
 
 namespace gnngls {
 
+#ifndef GLS_PERTURB_PRIO
+#define GLS_PERTURB_PRIO 3           // s_setprio of the wavefront that carries the perturbation phase
+#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
 #endif
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             STAMP_BEGIN();
             // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
             // waves of the other resident workgroups on the same SIMD: give it priority while it runs
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(GLS_PERTURB_PRIO);
             bool any_moved = false;
             int moves = 0;
             long long steps = 0;
@@ -1328,8 +1331,14 @@ int gls_block_threads(int n, int store) {
 }
 
 int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, size_t lds) {
-    if (store == GLS_STORE_TRI) return TriStore<int32_t>::kWavesPerSimd;
     if (store == GLS_STORE_GLOBAL) return GlobalStore::kWavesPerSimd;
+    if (store == GLS_STORE_TRI) {
+        // LDS-penalty store: the 128-VGPR build (no scratch) while it keeps the batch resident, else the 80-VGPR one
+        const int waves = threads / kWave;
+        const int by_lds = (int)((160 * 1024) / lds);
+        const int per_cu4 = by_lds < 16 / waves ? by_lds : 16 / waves;
+        return (batch > 0 && per_cu4 >= 1 && (long)per_cu4 * num_cus >= batch) ? 4 : TriStore<int32_t>::kWavesPerSimd;
+    }
     // compact store: the 128-VGPR build unless the batch only fits with 8 waves per SIMD
     const int waves = threads / kWave;
     const int by_lds = (int)((160 * 1024) / lds);
@@ -1378,7 +1387,8 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
     if (store == GLS_STORE_TRI && penalty_bits == 16)
         return launch_gls_f<TriStore<uint16_t>, TriStore<uint16_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     if (store == GLS_STORE_TRI)
-        return launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+        return wps == 4 ? launch_gls_f<TriStore<int32_t>, 4>(A, lds, threads, first_improvement, stream)
+                        : launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
 }
 

@@ -51,7 +51,7 @@ def test_forward_golden(n):
     assert_regret_close(y.cpu().numpy(), g["y"])
 
 
-@pytest.mark.parametrize("n,B", [(3, 4), (4, 3), (33, 3), (50, 2), (65, 2), (100, 2)])
+@pytest.mark.parametrize("n,B", [(3, 4), (4, 3), (33, 3), (50, 2), (65, 2), (100, 2), (150, 1)])   # 150: head-split gat_rows
 def test_forward_batch_vs_oracle(n, B):
     """HIP fp32 forward vs the CPU oracle on seeded random batches.
 
