@@ -356,6 +356,26 @@ def test_full_size_batch_properties(ops):
     assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
 
 
+def test_batch_larger_than_the_device_capacity(ops):
+    """gnngls_gls_run takes any B: workgroups beyond the resident capacity (1024 at TSP100) start when a slot frees up and
+    get the full time limit from their own start, so 1030 instances take two rounds; every result is valid."""
+    n, B, limit = 100, 1030, 0.3
+    assert ops.gls_resident_capacity(n) == 1024
+    D, _ = random_instances(np.random.default_rng(21), B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=limit)
+    t1.record(); torch.cuda.synchronize()
+    assert 2 * limit * 1000.0 * 0.95 < t0.elapsed_time(t1) < 2 * limit * 1000.0 + 1500.0
+    assert (r.status == 0).all() and (r.outer_iters > 50).all() and (r.best_cost < cost).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all() and (bt[:, -1] == 0).all()
+    assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("n,B,limit,min_iters", [(50, 128, 1.0, 200), (200, 256, 2.0, 20)])
 def test_config_size_batch_properties(ops, n, B, limit, min_iters):
     """BASELINE configs[1] (TSP50 x 128) and configs[4] (TSP200 x 256 per GPU) at full size in wall-clock mode: one
