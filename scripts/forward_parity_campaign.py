@@ -34,6 +34,8 @@ def main():
             failed.append((n, B, str(e)[:160]))
     print(f"{args.cases} random (n, batch) forwards checked at 1e-5 against the fp64 oracle, {len(failed)} failures, "
           f"{time.time() - t0:.0f} s")
+    print(f"cases that needed the small-graph clause (n < 20, 3x the fp32 reference's own error): "
+          f"{sorted(set((n, i) for n, i, _, _ in T.ESCAPES))}")
     for f in failed:
         print("FAIL", f)
     sys.exit(1 if failed else 0)

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RTOL = 1e-5
+ESCAPES = []      # (n, instance, max err, fp32 reference's own err) of cases that passed on the small-graph clause only
 
 
 def assert_regret_close(y, ref):
@@ -59,8 +60,10 @@ def test_forward_batch_vs_oracle(n, B):
     the exact value both fp32 implementations approximate.  A plain fp32 evaluation of the
     reference's own graph (the fp32 oracle, different summation order) is itself only within
     3e-6 .. 1.3e-5 of that value (worst for tiny ill-conditioned graphs such as n=4 where the
-    output is a small difference of large activations), so for such cases the HIP result is
-    required to be no further from the exact value than 3x the fp32 reference's own rounding error."""
+    output is a small difference of large activations), so for graphs smaller than every BASELINE
+    config (n < 20) the HIP result may instead be no further from the exact value than 3x the fp32
+    reference's own rounding error.  From n = 20 up the 1e-5 bound is asserted with no alternative.
+    ESCAPES collects the cases that needed the alternative (read by scripts/forward_parity_campaign.py)."""
     import copy
     from gnngls_amd.models import LineGraph
     from oracle import model_oracle as mo
@@ -79,7 +82,10 @@ def test_forward_batch_vs_oracle(n, B):
             err = np.abs(y[b] - ref64)
             bound = RTOL * np.abs(ref64) + RTOL * np.abs(ref64).max()
             ref_err = np.abs(ref32 - ref64).max()
-            assert (err <= bound).all() or err.max() <= 3.0 * ref_err, \
+            strict_ok = bool((err <= bound).all())
+            if not strict_ok and n < 20:
+                ESCAPES.append((n, b, float(err.max()), float(ref_err)))
+            assert strict_ok or (n < 20 and err.max() <= 3.0 * ref_err), \
                 f"n={n} b={b}: max err {err.max():.3e} (bound {bound.min():.3e}); fp32 reference's own error {ref_err:.3e}"
             # and directly against the fp32 reference path, the form the north star states -- wherever that path is itself
             # a usable yardstick (its own rounding error well inside the bar; not so for some tiny ill-conditioned graphs)
