@@ -560,42 +560,55 @@ __device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *
     }
 }
 
-// ---- lean "row on the lane" scans (best improvement, symmetric stores, n <= 127) -------------------------------------
-// The descent is bound by vector-instruction issue (8 waves per SIMD, ~2.7 of them ready at any time), not by LDS
+// ---- lean "row on the lane" scans (best improvement, symmetric stores, n <= 255) -------------------------------------
+// The descent is bound by vector-instruction issue (VALU ~76 % busy at full residency, LDS ~30 %), not by LDS
 // bandwidth: what counts is the number of VALU instructions per evaluation.  These versions keep the row-on-the-lane
 // mapping (lane l owns tour row i = 1 + 64 rb + l; the wavefront walks the other index uniformly) and strip the inner
-// loop to the arithmetic of the reference plus one triangular index:
-//   * the wave-uniform operands of a step (tour node, its triangular row offset, the tour-edge length) never touch
-//     LDS inside the loop: every lane keeps positions l and l + 64 of the tour / edge-length arrays in registers
-//     (loaded once per scan) and the step broadcasts them with v_readlane into SGPRs;
+// loop to the arithmetic of the reference plus one add/add/max address:
+//   * the tour node of a step is wave-uniform: every lane keeps positions l, l + 64, ... of the tour in registers
+//     (loaded once per scan) and the step broadcasts it with v_readlane into an SGPR, where its triangular row
+//     address is scalar arithmetic; the tour-edge length of the step is one LDS read at a wave-uniform address
+//     (a broadcast read: the LDS pipe has the headroom, the vector ALU does not);
+//   * the packed-triangle address of a pair needs no compare/select (tri_addr_max below): 3 VALU instead of 5;
 //   * relocate is enumerated by target EDGE k = (t[k], t[k+1]) instead of by j: for i < j the reference inserts
 //     between t[j], t[j+1] (k = j), for i > j between t[j-1], t[j] (k = j - 1) (operators.py:91-96), so
 //     delta(i, k) = ((base_i - Ef[k+1]) + D[t[k], b]) + D[b, t[k+1]] has ONE form, no per-lane selects, and
 //     D[b, t[k+1]] of step k is D[t[k+1], b] of step k + 1 (symmetric store: same bits): one random LDS read per step;
 //   * within a lane the keys (i, j) ascend, so "first minimum wins" is a plain strict `delta < best` (no key compare);
-//     np.isclose is only evaluated for a candidate that already beats the lane's best.
-// Same deltas (same operand order), same keys, same arg-min as the scans above.
+//     np.isclose and the excluded positions of a row (|i-j| < 2 in 2-opt, three targets in relocate) are only
+//     evaluated for a candidate that already beats the lane's best; rows past the end carry delta = +inf and never do.
+// Same deltas (same operands in the same order, read from the same addresses), same keys, same arg-min as the scans above.
+// Measured (same box, outer iterations per instance in 2 s, TSP100 x 1024 noise / weight guide, TSP200 x 256, TSP50 x 128;
+// profiles/r02_ab_lean_scan_v2.log): select-free address 7.15k -> 7.46k / 11.96k -> 12.34k / 5.46k -> 5.61k / 9.96k -> 10.24k;
+// + edge lengths from LDS instead of two v_readlane 8.06k / 12.91k / 6.07k / 10.43k; + late validity 8.20k / 13.06k / 6.12k / 10.42k.
 template <int SL>
-struct LaneTour {      // positions lane, lane + 64, ... (SL slots) of the tour and of Ef in registers
+struct LaneTour {      // positions lane, lane + 64, ... (SL slots) of the tour in registers
     int t[SL];
-    double e[SL];
 };
 template <int SL, class TT>
-__device__ __forceinline__ LaneTour<SL> load_lane_tour(const TT *t, const double *Ef, int n, int lane) {
+__device__ __forceinline__ LaneTour<SL> load_lane_tour(const TT *t, int n, int lane) {
     LaneTour<SL> L;
 #pragma unroll
     for (int q = 0; q < SL; ++q) {
         const int p = lane + q * kWave <= n ? lane + q * kWave : n;
         L.t[q] = t[p];
-        L.e[q] = Ef[p];                                      // Ef[0] is never used
     }
     return L;
 }
 __device__ __forceinline__ int bcast_int(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
-__device__ __forceinline__ double bcast_f64(double v, int src_lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+// LDS byte addresses as integers: the lean scans fold the base and the element size into the per-lane / per-step terms
+typedef __attribute__((address_space(3))) const double lds_cf64_t;
+__device__ __forceinline__ int lds_byte_addr(const double *p) { return (int)(size_t)(lds_cf64_t *)p; }
+__device__ __forceinline__ double lds_read_f64(int byte_addr) { return *(lds_cf64_t *)(size_t)(unsigned)byte_addr; }
+// Packed-triangle address of the pair {x, y} without compare/select: with rx = base + 8 x(x-1)/2 and x8 = 8 x,
+//   max(rx + y8, ry + x8) is the address of D[max(x,y), min(x,y)] whenever x != y and x + y >= 3
+// (for x > y: (rx + y8) - (ry + x8) = 4 (x - y)(x + y - 3)).  The pairs {0,1} and {0,2} are the exceptions: callers keep
+// node 0 out of it (a lane whose own node is 0 passes rx = kNoRow so the other candidate always wins; a step whose
+// uniform node is 0 takes the exact index).
+constexpr int kNoRow = -(1 << 30);
+__device__ __forceinline__ int tri_addr_max(int rx, int x8, int ry, int y8) {
+    const int p = rx + y8, q = ry + x8;
+    return p > q ? p : q;
 }
 // position p (wave-uniform) -> tour node, from the lane-resident copies (v_readlane takes the lane index modulo 64)
 template <int SL>
@@ -638,7 +651,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
     const int part = __builtin_amdgcn_readfirstlane(wave - rb * per_rb);
     if (per_rb == 0 || rb >= RW) return;                     // callers guarantee nwaves >= RW; surplus waves idle
-    const LaneTour<SL> L = load_lane_tour<SL>(t, Ef, n, lane);
+    const LaneTour<SL> L = load_lane_tour<SL>(t, n, lane);
     const int i = 1 + rb * kWave + lane;
     const bool row_ok = i <= n - 1;                          // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
     const int ic = row_ok ? i : 1;
@@ -646,23 +659,28 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     double base = -Ef[ic];                                   // -D[a,b]
     base = base - Ef[ic + 1];                                // -D[b,c]
     base = base + s.dist(a, cc);                             // +D[a,c]
+    if (!row_ok) base = __builtin_inf();                     // delta = +inf: never below the best (bd <= 0)
     const int b2 = (b * (b - 1)) >> 1;
+    const int dbase = lds_byte_addr(s.d);
+    const int bx = dbase + 8 * b2, b8 = 8 * b;               // b = t[i] >= 1
     int k0, k1;
     chunk_range(0, n, per_rb, part, k0, k1);                 // target edges k = 0 .. n-1
     if (k0 >= k1) return;
     const int d0 = lane_tour_node(L, k0);
     double vd = s.dist_at(s.idx2(b, b2, d0, (d0 * (d0 - 1)) >> 1));       // D[t[k0], b]   (garbage, unused, where t[k0] == b)
-    // U steps at a time: all wave-uniform operands, indices and the U random distance reads are issued before the first
+    // U steps at a time: all wave-uniform operands, addresses and the U random distance reads are issued before the first
     // dependent add, so the LDS round trips of a group overlap (a step alone is a ~280-cycle dependent chain)
-    auto group = [&](int k, int te, double ee, auto ucount) {     // te / ee: the register slot holding positions k+1 .. k+U
+    auto group = [&](int k, int te, auto ucount, auto fast_addr) {        // te: the register slot holding positions k+1 .. k+U
         constexpr int U = decltype(ucount)::value;
+        constexpr bool FA = decltype(fast_addr)::value;      // every t[k+1] of the group is a node >= 1
         double ve[U], de[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e = bcast_int(te, k + u + 1);          // v_readlane uses the lane index modulo 64
             const int e2 = (e * (e - 1)) >> 1;               // wave-uniform: scalar ALU
-            de[u] = bcast_f64(ee, k + u + 1);                // D[t[k], t[k+1]]
-            ve[u] = s.dist_at(s.idx2(b, b2, e, e2));         // D[b, t[k+1]]
+            de[u] = Ef[k + u + 1];                           // D[t[k], t[k+1]]: wave-uniform address, one broadcast LDS read
+            if constexpr (FA) ve[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 8 * e2, 8 * e));
+            else ve[u] = s.dist_at(s.idx2(b, b2, e, e2));    // D[b, t[k+1]]
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -671,21 +689,29 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             delta = delta + vd;                              // +D[d,b]
             delta = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
-            // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
-            if (row_ok && (unsigned)(kk - i + 2) > 2u && delta < bd) {
-                if (!close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
+            if (delta < bd) {
+                // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
+                if ((unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
             }
         }
     };
     using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
     using U1 = std::integral_constant<int, 1>;
+    using FAST = std::integral_constant<bool, true>;
+    using EXACT = std::integral_constant<bool, false>;
+    const int k1f = k1 == n ? n - 1 : k1;                    // step k = n-1 meets t[n] = node 0: exact index, after the loops
 #pragma unroll
     for (int q = 0; q < SL; ++q) {                           // slot q holds positions 64q .. 64q+63, i.e. k + 1 of k in [64q-1, 64q+62]
         const int lo = q * kWave - 1, hi = q * kWave + kWave - 1;
         int k = k0 > lo ? k0 : lo;
-        const int ke = k1 < hi ? k1 : hi;
-        for (; k + GLS_LEAN_UNROLL <= ke; k += GLS_LEAN_UNROLL) group(k, L.t[q], L.e[q], UN{});
-        for (; k < ke; ++k) group(k, L.t[q], L.e[q], U1{});
+        const int ke = k1f < hi ? k1f : hi;
+        for (; k + GLS_LEAN_UNROLL <= ke; k += GLS_LEAN_UNROLL) group(k, L.t[q], UN{}, FAST{});
+        for (; k < ke; ++k) group(k, L.t[q], U1{}, FAST{});
+    }
+    if (k1f != k1) {                                         // keys ascend with k within a lane: the last step stays last
+#pragma unroll
+        for (int q = 0; q < SL; ++q)                         // the slot that holds position n
+            if (n / kWave == q) group(n - 1, L.t[q], U1{}, EXACT{});
     }
 }
 
@@ -701,28 +727,31 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     int rb, part, parts;
     assign_waves(len, RW, nwaves, wave, rb, part, parts);
     rb = __builtin_amdgcn_readfirstlane(rb); part = __builtin_amdgcn_readfirstlane(part); parts = __builtin_amdgcn_readfirstlane(parts);
-    const LaneTour<SL> L = load_lane_tour<SL>(t, Eb, n, lane);
+    const LaneTour<SL> L = load_lane_tour<SL>(t, n, lane);
     const int i = 1 + rb * kWave + lane;
     const bool row_ok = i <= n - 3;
     const int ic = row_ok ? i : 1;
     const int a = t[ic], b = t[ic - 1];
     const int a2 = (a * (a - 1)) >> 1, b2 = (b * (b - 1)) >> 1;
-    const double eab = Eb[ic];                               // D[a,b]
+    const double eab = row_ok ? Eb[ic] : -__builtin_inf();   // D[a,b]; rows past the end: delta = +inf, never below the best
+    const int dbase = lds_byte_addr(s.d);
+    const int ax = dbase + 8 * a2, a8 = 8 * a;               // a = t[i] >= 1; c = t[j] >= 1 and d = t[j-1] >= 1 (j >= 3)
+    const int bx = b == 0 ? kNoRow : dbase + 8 * b2, b8 = 8 * b;      // b = t[i-1] is node 0 on row 1: D[0,d] sits in row d, column 0
     int j0, j1;
     chunk_range(3 + rb * kWave, n, parts, part, j0, j1);     // j = j0 .. j1-1
     if (j0 >= j1) return;
     int d = lane_tour_node(L, j0 - 1);
     int d2 = (d * (d - 1)) >> 1;
-    auto group = [&](int j, int tj, double ej, auto ucount) {     // tj / ej: the register slot holding positions j .. j+U-1
+    auto group = [&](int j, int tj, auto ucount) {           // tj: the register slot holding positions j .. j+U-1
         constexpr int U = decltype(ucount)::value;
         double vac[U], vbd[U], ecd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = bcast_int(tj, j + u);
             const int c2 = (c * (c - 1)) >> 1;
-            ecd[u] = bcast_f64(ej, j + u);                   // D[c,d]
-            vac[u] = s.dist_at(s.idx2(a, a2, c, c2));        // D[a,c]
-            vbd[u] = s.dist_at(s.idx2(b, b2, d, d2));        // D[b,d]
+            ecd[u] = Eb[j + u];                              // D[c,d]: wave-uniform address, one broadcast LDS read
+            vac[u] = lds_read_f64(tri_addr_max(ax, a8, dbase + 8 * c2, 8 * c));      // D[a,c]
+            vbd[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 8 * d2, 8 * d));      // D[b,d]
             d = c; d2 = c2;
         }
 #pragma unroll
@@ -730,8 +759,8 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
             delta = delta - eab;
             delta = delta - ecd[u];
-            if (row_ok && j + u >= i + 2 && delta < bd) {
-                if (!close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
+            if (delta < bd) {                                // j < i + 2 holds the mirrored move's delta: rarely below the best either
+                if (j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
             }
         }
     };
@@ -741,8 +770,8 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     for (int q = 0; q < SL; ++q) {                           // slot q holds positions j in [64q, 64q+63]
         int j = j0 > q * kWave ? j0 : q * kWave;
         const int je = j1 < (q + 1) * kWave ? j1 : (q + 1) * kWave;
-        for (; j + GLS_LEAN_UNROLL <= je; j += GLS_LEAN_UNROLL) group(j, L.t[q], L.e[q], UN{});
-        for (; j < je; ++j) group(j, L.t[q], L.e[q], U1{});
+        for (; j + GLS_LEAN_UNROLL <= je; j += GLS_LEAN_UNROLL) group(j, L.t[q], UN{});
+        for (; j < je; ++j) group(j, L.t[q], U1{});
     }
 }
 
