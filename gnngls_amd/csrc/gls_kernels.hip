@@ -337,7 +337,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS control block shared by the workgroup
+// LDS control block shared by the workgroup.  red_d / red_k are the exchange slots of block_reduce_best; the
+// best-improvement descent reuses the first 24 + 12 bytes as the three rotating (value, key) slots of block_reduce_best_lds.
 struct Ctl {
     double red_d[2][8];
     int red_k[2][8];
@@ -558,6 +559,44 @@ __device__ __forceinline__ void scan_relocate_a2a_rowlane(const S &s, const TT *
             }
         }
     }
+}
+
+// Workgroup arg-min of (delta, key) for the best-improvement descent, by LDS atomics instead of DPP chains: the lanes
+// that may hold the minimum issue ONE ds_min_u64 on the order-preserving image of their delta; after a barrier the lanes
+// that hold the minimum issue one ds_min_u32 on their key.  Same result as the lexicographic min of block_reduce_best (value,
+// then key); of its three dependent 6-step DPP reductions per wavefront, the per-wave exchange and the compare chain over the
+// waves' results (~100 dependent instructions, ~2,600 cycles per scan at four waves per SIMD: profiles/r02_stamps_per_wave.log)
+// one DPP reduction, two LDS atomics and one extra barrier remain.  Measured (same box, outer iterations per instance):
+// TSP100 x 1024 +1.4 .. +1.9 %, TSP50 x 128 +4.8 %, TSP200 x 256 +1.6 %, LDS-penalty store x 512 +5.3 % (profiles/r02_ab_lds_atomic_argmin.log).  Three slots rotate: slot `phase` is in use, the next one is reset by
+// thread 0 before the first barrier (its last readers passed the previous reduction's barrier long ago).
+__device__ __forceinline__ void block_reduce_lds_init(Ctl *ctl, int tid) {
+    if (tid < 3) {
+        reinterpret_cast<unsigned long long *>(&ctl->red_d[0][0])[tid] = ~0ull;
+        reinterpret_cast<unsigned *>(&ctl->red_k[0][0])[tid] = 0x7fffffffu;
+    }
+}
+__device__ __forceinline__ void block_reduce_best_lds(Ctl *ctl, int &phase, int tid, double &d, int &k) {
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+    typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+    lds_u64_t *av = (lds_u64_t *)reinterpret_cast<unsigned long long *>(&ctl->red_d[0][0]);
+    lds_u32_t *ak = (lds_u32_t *)reinterpret_cast<unsigned *>(&ctl->red_k[0][0]);
+    const int sl = phase, nx = phase == 2 ? 0 : phase + 1;
+    const bool cand = k != kNoKey;
+    const unsigned long long sk = sortable(d);
+    // 64 lanes on one address serialise in the LDS atomic unit (with every candidate lane going, a noise guide lost 3 %):
+    // one DPP min over the high words first, and only the lanes that share the wavefront's smallest high word go
+    const unsigned hi = cand ? (unsigned)(sk >> 32) : 0xffffffffu;
+    const unsigned mhi = wave_umin(hi);
+    if (cand && hi == mhi) __hip_atomic_fetch_min(&av[sl], sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid == 0) { av[nx] = ~0ull; ak[nx] = 0x7fffffffu; }
+    __syncthreads();
+    phase = nx;
+    const unsigned long long m = av[sl];
+    if (m == ~0ull) { k = kNoKey; return; }                  // no candidate in the workgroup (uniform)
+    if (cand && sk == m) __hip_atomic_fetch_min(&ak[sl], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    k = (int)ak[sl];
+    d = unsortable(m);
 }
 
 // ---- lean "row on the lane" scans (best improvement, symmetric stores, n <= 255) -------------------------------------
@@ -936,7 +975,8 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
                 else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             }
             STAMP_END(8);    // a2a scan (this wave's share)
-            block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
+            if (!FI && nwaves > 1) block_reduce_best_lds(ctl, phase, tid, bd, bk);
+            else block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
             STAMP_END(9);    // wave + workgroup arg-min (includes waiting for the slowest wave)
             STAMP_COUNT(11);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
@@ -1038,6 +1078,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     };
     if (tid == 0 && A.imp_len) A.imp_len[b] = 0;
 
+    if (!FI && nthr > kWave) { block_reduce_lds_init(ctl, tid); __syncthreads(); }
     STAMP_BEGIN();
     local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
@@ -1219,9 +1260,21 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         if (A.evals) A.evals[b] = evals;
         if (A.status) A.status[b] = status;
 #ifdef GLS_STAMPS
-        if (A.stamps) { long long *o = A.stamps + (size_t)b * 16; for (int q = 0; q < 16; ++q) o[q] = st.acc[q]; }
+        if (A.stamps) { long long *o = A.stamps + (size_t)b * 16; for (int q = 0; q < 12; ++q) if (q != 7) o[q] = st.acc[q]; }
 #endif
     }
+#ifdef GLS_STAMPS
+    // per-wavefront view of the descent (waves 1..3; wave 0 is slots 8 / 9) and where the hardware placed each wave:
+    // slot 12 = wave 1's arg-min + wait, slots 13..15 = scan cycles of waves 1..3, slot 7 = (SIMD id + 1) << 8 wave
+    if (A.stamps && lane == 0) {
+        long long *o = A.stamps + (size_t)b * 16;
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (wave < 8) atomicAdd((unsigned long long *)&o[7], (unsigned long long)(((hw >> 4) & 3) + 1) << (8 * wave));
+        if (wave == 1) o[12] = st.acc[9];
+        if (wave >= 1 && wave <= 3) o[12 + wave] = st.acc[8];
+    }
+#endif
     if (A.penalty_out) {
         int32_t *po = A.penalty_out + (size_t)b * nn;
         for (size_t q = tid; q < nn; q += nthr) {

@@ -26,10 +26,10 @@ tc = int(os.environ.get("TRACE_CAP", "0"))
 r = ops.gls_run(D, g, init, cost, penalty_bits=int(os.environ.get('BITS', '0')), perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
 torch.cuda.synchronize()
+raw = stamps.cpu().numpy()
 st = stamps.double().mean(0).cpu().numpy()
 assert st.sum() > 0, 'library was not built with GNNGLS_EXTRA_FLAGS=-DGLS_STAMPS'
 names = ["utility argmax", "o2a scan (+pen, pos search)", "o2a reduce", "apply+reload", "phase tail", "descent (LS)", "steps"]
-st[1] += st[12]
 st[5] += st[8] + st[9] + st[10]          # the descent's sub-stamps restart the clock: slot 5 only holds the remainder
 tot = st[:6].sum()
 it = r.outer_iters.double().mean().item()
@@ -39,5 +39,10 @@ for k in range(6):
 print(f"cycles per perturbation step (wave 0): {(st[0] + st[1] + st[2] + st[3]) / st[6]:.0f}")
 print(f"descent: scans/iter {st[11] / it:.2f}; per scan: scan {st[8] / st[11]:.0f}, arg-min+wait {st[9] / st[11]:.0f}, "
       f"apply+barrier {st[10] / st[11]:.0f} cycles (share of descent {100 * (st[8] + st[9] + st[10]) / max(st[5], 1):.0f}%)")
-print(f"fused rounds: load part {st[12] / it:.0f} cycles/iter")
+sc = max(st[11], 1)
+print(f"descent per wave, cycles per scan: scan w0 {st[8] / sc:.0f}  w1 {st[13] / sc:.0f}  w2 {st[14] / sc:.0f}  w3 {st[15] / sc:.0f};  "
+      f"arg-min+wait w0 {st[9] / sc:.0f}  w1 {st[12] / sc:.0f}")
+simd = [((raw[:, 7] >> (8 * w)) & 0xff) - 1 for w in range(4)]
+import collections
+print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.tolist() for x in simd])).most_common(6))
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
