@@ -645,6 +645,12 @@ __device__ __forceinline__ double lds_read_f64(int byte_addr) { return *(lds_cf6
 // node 0 out of it (a lane whose own node is 0 passes rx = kNoRow so the other candidate always wins; a step whose
 // uniform node is 0 takes the exact index).
 constexpr int kNoRow = -(1 << 30);
+// keeps a per-lane address term as ONE register the optimiser cannot look through: left alone it re-associates
+// (base + 8 r) + 8 y back into ((r + y) << 3) + base, one more vector instruction per address in the inner loops
+__device__ __forceinline__ int opaque_vgpr(int v) { asm volatile("" : "+v"(v)); return v; }
+// placed between an outer and an inner condition: keeps the inner one (and its operands) out of the common path --
+// without it the two side-effect-free tests are merged and both are evaluated for every candidate
+__device__ __forceinline__ void rare_path() { asm volatile(""); }
 __device__ __forceinline__ int tri_addr_max(int rx, int x8, int ry, int y8) {
     const int p = rx + y8, q = ry + x8;
     return p > q ? p : q;
@@ -701,7 +707,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     if (!row_ok) base = __builtin_inf();                     // delta = +inf: never below the best (bd <= 0)
     const int b2 = (b * (b - 1)) >> 1;
     const int dbase = lds_byte_addr(s.d);
-    const int bx = dbase + 8 * b2, b8 = 8 * b;               // b = t[i] >= 1
+    const int bx = opaque_vgpr(dbase + 8 * b2), b8 = opaque_vgpr(8 * b);      // b = t[i] >= 1
     int k0, k1;
     chunk_range(0, n, per_rb, part, k0, k1);                 // target edges k = 0 .. n-1
     if (k0 >= k1) return;
@@ -718,7 +724,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             const int e = bcast_int(te, k + u + 1);          // v_readlane uses the lane index modulo 64
             const int e2 = (e * (e - 1)) >> 1;               // wave-uniform: scalar ALU
             de[u] = Ef[k + u + 1];                           // D[t[k], t[k+1]]: wave-uniform address, one broadcast LDS read
-            if constexpr (FA) ve[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 8 * e2, 8 * e));
+            if constexpr (FA) ve[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 4 * e * (e - 1), 8 * e));   // 8 e(e-1)/2, no shift pair
             else ve[u] = s.dist_at(s.idx2(b, b2, e, e2));    // D[b, t[k+1]]
         }
 #pragma unroll
@@ -729,6 +735,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             delta = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
             if (delta < bd) {
+                rare_path();
                 // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
                 if ((unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
             }
@@ -774,23 +781,23 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     const int a2 = (a * (a - 1)) >> 1, b2 = (b * (b - 1)) >> 1;
     const double eab = row_ok ? Eb[ic] : -__builtin_inf();   // D[a,b]; rows past the end: delta = +inf, never below the best
     const int dbase = lds_byte_addr(s.d);
-    const int ax = dbase + 8 * a2, a8 = 8 * a;               // a = t[i] >= 1; c = t[j] >= 1 and d = t[j-1] >= 1 (j >= 3)
-    const int bx = b == 0 ? kNoRow : dbase + 8 * b2, b8 = 8 * b;      // b = t[i-1] is node 0 on row 1: D[0,d] sits in row d, column 0
+    const int ax = opaque_vgpr(dbase + 8 * a2), a8 = opaque_vgpr(8 * a);      // a = t[i] >= 1; c = t[j] >= 1 and d = t[j-1] >= 1 (j >= 3)
+    const int bx = opaque_vgpr(b == 0 ? kNoRow : dbase + 8 * b2), b8 = opaque_vgpr(8 * b);   // b = t[i-1] is node 0 on row 1: D[0,d] sits in row d, column 0
     int j0, j1;
     chunk_range(3 + rb * kWave, n, parts, part, j0, j1);     // j = j0 .. j1-1
     if (j0 >= j1) return;
     int d = lane_tour_node(L, j0 - 1);
-    int d2 = (d * (d - 1)) >> 1;
+    int d2 = dbase + 4 * d * (d - 1);
     auto group = [&](int j, int tj, auto ucount) {           // tj: the register slot holding positions j .. j+U-1
         constexpr int U = decltype(ucount)::value;
         double vac[U], vbd[U], ecd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = bcast_int(tj, j + u);
-            const int c2 = (c * (c - 1)) >> 1;
             ecd[u] = Eb[j + u];                              // D[c,d]: wave-uniform address, one broadcast LDS read
-            vac[u] = lds_read_f64(tri_addr_max(ax, a8, dbase + 8 * c2, 8 * c));      // D[a,c]
-            vbd[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 8 * d2, 8 * d));      // D[b,d]
+            const int c2 = dbase + 4 * c * (c - 1);          // wave-uniform row address 8 c(c-1)/2: scalar ALU
+            vac[u] = lds_read_f64(tri_addr_max(ax, a8, c2, 8 * c));      // D[a,c]
+            vbd[u] = lds_read_f64(tri_addr_max(bx, b8, d2, 8 * d));      // D[b,d]
             d = c; d2 = c2;
         }
 #pragma unroll
@@ -799,6 +806,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             delta = delta - eab;
             delta = delta - ecd[u];
             if (delta < bd) {                                // j < i + 2 holds the mirrored move's delta: rarely below the best either
+                rare_path();
                 if (j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
             }
         }

@@ -1,15 +1,15 @@
 cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gls_gpu.py tests/test_gls_fuzz_gpu.py tests/test_search_progress_gpu.py -m gpu -q -x 2>&1 | tail -2
 for rep in 1 2; do
-for v in _prev "" _pref; do
+for v in _prev ""; do
   export GNNGLS_HIP_SO=$PWD/gnngls_amd/libgnngls_hip$v.so
   echo "=== variant '$v'"
   timeout 120 python scripts/probe_gls.py 100 1024 2.0 0 noise 2>&1 | grep "n="
   timeout 120 python scripts/probe_gls.py 100 1024 2.0 0 weight 2>&1 | grep "n="
   timeout 120 python scripts/probe_gls.py 50 128 1.0 0 noise 2>&1 | grep "n="
   timeout 120 python scripts/probe_gls.py 50 2048 1.0 0 weight 2>&1 | grep "n="
+  timeout 120 python scripts/probe_gls.py 20 1000 1.0 0 weight 2>&1 | grep "n="
   timeout 120 python scripts/probe_gls.py 200 256 2.0 0 weight 2>&1 | grep "n="
   timeout 120 python scripts/probe_gls.py 100 512 1.0 16 weight 2>&1 | grep "n="
 done
 done
-export GNNGLS_HIP_SO=$PWD/gnngls_amd/libgnngls_hip_pref.so
-timeout 900 python -m pytest tests/test_gls_gpu.py tests/test_gls_fuzz_gpu.py tests/test_search_progress_gpu.py -m gpu -q -x 2>&1 | tail -2
