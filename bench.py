@@ -371,7 +371,8 @@ def main():
                                                          "hbm_gbs", "clock_ghz", "source") if k in traffic},
                          "note": "LDS bytes are algorithmic (48 B per 2-opt, 68 B per relocate evaluation, SURVEY 8d).  The counters "
                                  "(pmc, committed PMC passes on the same kernel) say what actually binds it at full residency: "
-                                 "vector-instruction issue (VALU pipe ~76 % busy), with the LDS array ~28 % busy and HBM < 1 %.  "
+                                 "vector-instruction issue first (VALU pipe %.0f %% busy), the LDS pipe second (%.0f %% busy), HBM ~1 %%.  "
+                                 % (100 * traffic.get("valu_busy_frac", float("nan")), 100 * traffic.get("lds_busy_frac", float("nan"))) +
                                  "The forward kernels' MFMA / HBM rooflines are under `kernels`"},
             "gls_ms_per_rank": [p[0].item() for p in per_rank],
             "kernels": kern, "forward_kernels_ms_total": fwd_ms,
