@@ -47,6 +47,7 @@ def main():
     e = {
         "hbm_bytes_per_instance_second": hbm_per_inst_s,
         "hbm_gbs": hbm_per_inst_s * instances / 1e9,
+        "hbm_gbs_fetch_doubled": (2 * fetch_b / t_f + write_b / t_w) / 1e9,      # upper bound: the guide's x2 applied anyway
         "lds_busy_frac": lds["SQ_LDS_IDX_ACTIVE"] / (cus * t_l * clock),
         "lds_bank_conflict_frac": lds["SQ_LDS_BANK_CONFLICT"] / lds["SQ_LDS_IDX_ACTIVE"],
         "valu_busy_frac": iss["SQ_ACTIVE_INST_VALU"] * 4 / (simds * t_i * clock),     # SQ cycle counters tick once per 4 cycles
