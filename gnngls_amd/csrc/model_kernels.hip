@@ -18,6 +18,7 @@
 //                           softmax shift is the exact row maximum (top-2 trick excludes k=j)
 //       (the log-sum-exp merge of the two row partials + skip + BN1 is fused into ffn_fused_kernel)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -27,6 +28,10 @@ namespace gnngls {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 (two lanes of work per instruction); the compiler scalarises <2 x float> arithmetic next to scalar selects
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 constexpr int kD = 128;        // embed_dim
 constexpr int kH = 8;          // heads
@@ -384,16 +389,25 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
             ner[u] = -er[u];
             direct = direct || top[h * 4 + 3] != 0.f;          // wave-uniform
         }
-        // two source groups (2 x 4 sources) per iteration: 8 independent weights + 8 MFMAs in flight
+        // two source groups (2 x 4 sources) per iteration: 8 independent weights + 8 MFMAs in flight.  The loop is bound by
+        // the vector ALU beside the matrix pipe (one weight feeds only 16 features), so the weight arithmetic is packed:
+        // both products and the denominator sums run two heads per instruction (v_pk_mul_f32 / v_pk_add_f32), and the
+        // self-loop / padding mask is only applied in the iterations that can meet either (the destination tile's own
+        // sources and the last, partial group) -- same values, same order of the sums.
         if (!direct) {
-            for (int s0 = 0; s0 < ns; s0 += 8) {
+            static_assert(HU == 4, "two packed head pairs per unit");
+            f32x2 cpos2[2] = {f32x2{cpos[0], cpos[1]}, f32x2{cpos[2], cpos[3]}};
+            f32x2 cneg2[2] = {f32x2{cneg[0], cneg[1]}, f32x2{cneg[2], cneg[3]}};
+            f32x2 ws2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+            auto body = [&](int s0, auto masked) {
+                constexpr bool MASK = decltype(masked)::value;
                 int sidx[2]; bool live[2];
                 f32x4 e[2], ea[2], eb[2];
                 float bv[2][HU];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const int s = s0 + 4 * g + kq;
-                    sidx[g] = s < ns ? s : ns - 1;
+                    sidx[g] = MASK ? (s < ns ? s : ns - 1) : s;
                     live[g] = (s < ns) && (s != js);              // no self loop, no padding
                     e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * HS + h0);
                     ea[g] = *reinterpret_cast<const f32x4 *>(eaS + sidx[g] * HS + h0);
@@ -404,15 +418,36 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                    for (int u = 0; u < HU; ++u) {
-                        const float wp = ea[g][u] * cpos[u], wn = eb[g][u] * cneg[u];
-                        float w = e[g][u] > ner[u] ? wp : wn;
-                        w = live[g] ? w : 0.f;
-                        ws[u] += w;
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv[g][u], acc[u], 0, 0, 0);
+                    for (int hp = 0; hp < 2; ++hp) {
+                        const f32x2 ea2 = hp == 0 ? f32x2{ea[g][0], ea[g][1]} : f32x2{ea[g][2], ea[g][3]};
+                        const f32x2 eb2 = hp == 0 ? f32x2{eb[g][0], eb[g][1]} : f32x2{eb[g][2], eb[g][3]};
+                        const f32x2 wp = pk_mul(ea2, cpos2[hp]), wn = pk_mul(eb2, cneg2[hp]);
+                        f32x2 w;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int u = 2 * hp + c;
+                            float x = e[g][u] > ner[u] ? wp[c] : wn[c];
+                            if (MASK) x = live[g] ? x : 0.f;
+                            w[c] = x;
+                        }
+                        ws2[hp] = pk_add(ws2[hp], w);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            acc[2 * hp + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c], bv[g][2 * hp + c], acc[2 * hp + c], 0, 0, 0);
                     }
                 }
-            }
+            };
+            // sources in ascending order, as four runs (one loop per body: a per-iteration choice between the two bodies
+            // costs a copy of the 16 accumulator registers every iteration): below the tile's own destinations, the two
+            // groups that contain them, above them, and the last partial group
+            const int t0 = dt * 16;
+            int s0 = 0;
+            for (; s0 < t0; s0 += 8) body(s0, std::false_type{});                      // t0 <= ns - 1: full groups
+            for (; s0 < t0 + 16 && s0 < ns; s0 += 8) body(s0, std::true_type{});
+            for (; s0 + 8 <= ns; s0 += 8) body(s0, std::false_type{});
+            for (; s0 < ns; s0 += 8) body(s0, std::true_type{});
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) { ws[2 * hp] = ws2[hp][0]; ws[2 * hp + 1] = ws2[hp][1]; }
         } else {
             for (int s0 = 0; s0 < ns; s0 += 8) {
                 int sidx[2]; bool live[2];
