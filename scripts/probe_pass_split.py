@@ -1,3 +1,9 @@
+#!/usr/bin/env python
+"""Diagnostic used for profiles/r02_stamps_guided_pass_split.log: reads the stamp slots 7 / 12..15 of a library built with
+-DGLS_STAMPS AND with clock reads placed inside scan_two_opt_o2a_guided (after the tour reads, after the loads are issued,
+after `s_waitcnt vmcnt(0) lgkmcnt(0)`, after `consider`), accumulated into those slots.  That instrumentation is not kept in
+the tree (it perturbs the loop it measures); the log describes it.  With the plain -DGLS_STAMPS build the slots hold the
+per-wave descent figures instead (scripts/probe_gls_stamps.py)."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from gnngls_amd import ops, _lib
