@@ -71,3 +71,24 @@ def test_instance_blocks_and_best_known_file(tmp_path):
     assert b.load_best_known(path, 6, 7, 1000, 1200)[0] is None         # beyond the covered part of block 1
     assert b.load_best_known(path, 6, 8, 0, 10)[0] is None              # another seed
     assert b.load_best_known(str(tmp_path / "none.npz"), 6, 7, 0, 10)[0] is None
+
+
+def test_committed_pmc_figures_follow_from_the_committed_counter_files():
+    """profiles/traffic_r02.json's gls_kernel entry (what bench.py prints as roofline.pmc / roofline.traffic) is exactly what
+    scripts/pmc_summary.py derives from the counter CSVs it names -- no hand-edited numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    entry = json.load(open(os.path.join(root, "profiles", "traffic_r02.json")))["gls_kernel"]
+    src = entry["source"].split("/*_counter_collection.csv")[0]
+    assert os.path.isdir(os.path.join(root, src)), src
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_summary.py"), os.path.join(root, src)],
+                         capture_output=True, text=True, check=True).stdout
+    derived = json.loads(out[out.index("{"):out.rindex("}") + 1])
+    for k, v in derived.items():
+        if isinstance(v, float):
+            assert abs(entry[k] - v) <= 1e-9 * max(1.0, abs(v)), k
+        else:
+            assert entry[k] == v, k
