@@ -586,8 +586,10 @@ int gnngls_debug_set_penalty16_limit(int limit) {
 }
 
 int gnngls_debug_set_gls_threads(int threads) {
-    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024)
-        return fail(GNNGLS_ERR_ARG, "gls threads override must be 0 (default policy), 64, 128, 256, 512 or 1024");
+    // 1024 is not accepted: only the 128-VGPR instantiations are compiled for 16-wave workgroups (the default policy
+    // picks them itself where a workgroup owns a CU); the 64- and 80-VGPR builds are bounded at 512 threads
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512)
+        return fail(GNNGLS_ERR_ARG, "gls threads override must be 0 (default policy), 64, 128, 256 or 512");
     gnngls::gls_set_block_threads_override(threads);
     return GNNGLS_OK;
 }

@@ -32,6 +32,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "gls_kernels.h"
@@ -1251,14 +1252,17 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
     // ---- outputs ----
     for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = (int32_t)bt[p];
-    if (tid == 0 && A.imp_len && A.imp_cap > 0) {
-        // terminal entry (returned best, end of the search, completed iterations): always the last one, and always
-        // stored -- if the improvements overflowed the buffer it takes the last slot
+    if (tid == 0 && A.imp_len) {
+        // terminal entry (returned best, end of the search, completed iterations): always the last one, always counted
+        // (imp_len = improvements + 1 also when imp_cap == 0, as the header says) and, given a buffer, always stored --
+        // if the improvements overflowed the buffer it takes the last slot
         const int l = A.imp_len[b];
-        const size_t q = (size_t)b * A.imp_cap + (l < A.imp_cap ? l : A.imp_cap - 1);
-        if (A.imp_cost) A.imp_cost[q] = best_cost;
-        if (A.imp_time) A.imp_time[q] = (float)((double)(wall_clock64() - t_start) * 1e-8);
-        if (A.imp_iter) A.imp_iter[q] = iter_i;
+        if (A.imp_cap > 0) {
+            const size_t q = (size_t)b * A.imp_cap + (l < A.imp_cap ? l : A.imp_cap - 1);
+            if (A.imp_cost) A.imp_cost[q] = best_cost;
+            if (A.imp_time) A.imp_time[q] = (float)((double)(wall_clock64() - t_start) * 1e-8);
+            if (A.imp_iter) A.imp_iter[q] = iter_i;
+        }
         A.imp_len[b] = l + 1;
     }
     if (tid == 0) {
@@ -1400,11 +1404,12 @@ size_t gls_lds_bytes(int n, int store, int penalty_bits) {
     return off;
 }
 
-static int g_threads_override = 0;      // experiments only (gnngls_debug_set_gls_threads)
-void gls_set_block_threads_override(int threads) { g_threads_override = threads; }
+static std::atomic<int> g_threads_override{0};      // experiments only (gnngls_debug_set_gls_threads)
+void gls_set_block_threads_override(int threads) { g_threads_override.store(threads, std::memory_order_relaxed); }
 
 int gls_block_threads(int n, int store) {
-    if (g_threads_override > 0) return g_threads_override;
+    const int forced = g_threads_override.load(std::memory_order_relaxed);
+    if (forced > 0) return forced;
     if (n <= 24) return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;

@@ -83,6 +83,26 @@ def line_graph_networkx(n):
     return LineGraph(n, torch.tensor(src, dtype=torch.int64), torch.tensor(dst, dtype=torch.int64), e)
 
 
+def line_graph_arcs_closed_form(n):
+    """The same directed arc set as line_graph_networkx(n), from the closed-form rule (destination {i,j} has the
+    in-neighbours {i,k} and {k,j}, k not in {i,j}), as numpy index arithmetic -- networkx needs minutes and gigabytes for
+    the 3.9 million undirected line-graph edges of K_200.  Arcs are sorted by destination (then source), which is what
+    gat_aggregate_edge_list's chunked form needs.  tests/test_model_oracle.py checks the arc sets are equal for small n."""
+    e = np.array(edge_list(n), dtype=np.int64)
+    rank = np.full((n, n), -1, dtype=np.int64)
+    rank[e[:, 0], e[:, 1]] = np.arange(len(e))
+    rank[e[:, 1], e[:, 0]] = np.arange(len(e))
+    i, j = e[:, 0], e[:, 1]
+    k = np.arange(n)
+    keep = (k[None, :] != i[:, None]) & (k[None, :] != j[:, None])          # [N, n]
+    via_i = rank[i[:, None], k[None, :]]                                    # {i,k}
+    via_j = rank[k[None, :], j[:, None]]                                    # {k,j}
+    src = np.concatenate([via_i[keep].reshape(len(e), n - 2), via_j[keep].reshape(len(e), n - 2)], axis=1)
+    src.sort(axis=1)
+    dst = np.repeat(np.arange(len(e)), 2 * (n - 2))
+    return LineGraph(n, torch.from_numpy(src.reshape(-1)), torch.from_numpy(dst), torch.from_numpy(e))
+
+
 def batch_line_graphs(n, batch):
     """Disjoint union of `batch` copies of the line graph of K_n -- what dgl.batch (train.py:118-121) hands to the
     model: node ids of instance b are offset by b*N, arcs never cross instances."""
@@ -127,6 +147,8 @@ def gat_aggregate_edge_list(ft, el, er, src, dst, slope=0.2):
     """Formulation A: per-arc scores, scatter max / sum over destinations (what DGL's
     apply_edges(u_add_v) -> leaky_relu -> edge_softmax -> update_all(u_mul_e, sum) computes)."""
     N, H, F = ft.shape
+    if src.numel() * H * F > _CHUNK_ELEMS:
+        return _gat_aggregate_chunked(ft, el, er, src, dst, slope)
     e = torch.nn.functional.leaky_relu(el[src] + er[dst], slope)            # [E,H]
     idx = dst[:, None].expand(-1, H)
     m = torch.full((N, H), -math.inf, dtype=ft.dtype).scatter_reduce(0, idx, e, reduce="amax", include_self=True)
@@ -134,6 +156,35 @@ def gat_aggregate_edge_list(ft, el, er, src, dst, slope=0.2):
     s = torch.zeros((N, H), dtype=ft.dtype).index_add_(0, dst, p)
     a = p / s[dst]
     out = torch.zeros((N, H, F), dtype=ft.dtype).index_add_(0, dst, a[:, :, None] * ft[src])
+    return out
+
+
+_CHUNK_ELEMS = 1 << 28       # [E,H,F] temporaries above this many elements (2 GiB in fp64) are built per destination range
+
+
+def _gat_aggregate_chunked(ft, el, er, src, dst, slope, arcs_per_chunk=1 << 20):
+    """gat_aggregate_edge_list for graphs whose [E,H,F] message tensor does not fit in memory (K_200: 7.9 million arcs x
+    128 features): the same formulas on consecutive destination ranges.  Needs arcs sorted by destination (every
+    destination's in-arcs then sit in one range, in their original order, so each range is the unchunked computation
+    restricted to those destinations)."""
+    N, H, F = ft.shape
+    assert bool((dst[1:] >= dst[:-1]).all()), "chunked aggregation needs arcs sorted by destination"
+    out = torch.zeros((N, H, F), dtype=ft.dtype)
+    E, a = src.numel(), 0
+    while a < E:
+        b = min(a + arcs_per_chunk, E)
+        if b < E:                                                # extend to the end of the last destination's run
+            b = int(torch.searchsorted(dst, dst[b - 1], right=True))
+        d0, d1 = int(dst[a]), int(dst[b - 1]) + 1
+        s_, d_ = src[a:b], dst[a:b] - d0
+        e = torch.nn.functional.leaky_relu(el[s_] + er[d0:d1][d_], slope)
+        idx = d_[:, None].expand(-1, H)
+        m = torch.full((d1 - d0, H), -math.inf, dtype=ft.dtype).scatter_reduce(0, idx, e, reduce="amax", include_self=True)
+        p = torch.exp(e - m[d_])
+        z = torch.zeros((d1 - d0, H), dtype=ft.dtype).index_add_(0, d_, p)
+        w = p / z[d_]
+        out[d0:d1] = torch.zeros((d1 - d0, H, F), dtype=ft.dtype).index_add_(0, d_, w[:, :, None] * ft[s_])
+        a = b
     return out
 
 

@@ -93,11 +93,14 @@ def progress_rows(res, k, full_trace):
         moves = int(res.moves[k])
         kept = min(moves, full_trace)
         rows = list(zip(res.trace_time[k, :kept].tolist(), res.trace_cost[k, :kept].tolist()))
-        if moves <= full_trace:
-            return rows, False
         t_cut = rows[-1][0] if rows else -1.0
     m = min(int(res.imp_len[k]), res.imp_cost.shape[1])
-    rows += [(dt, c) for dt, c in zip(res.imp_time[k, :m].tolist(), res.imp_cost[k, :m].tolist()) if dt > t_cut]
+    imp = list(zip(res.imp_time[k, :m].tolist(), res.imp_cost[k, :m].tolist()))
+    if full_trace > 0 and moves <= full_trace:
+        # complete per-move record: only the terminal entry (returned best, end of the search) is added, so that the
+        # record reaches the returned cost also when no move was accepted or the start tour was never improved
+        return rows + imp[-1:], False
+    rows += [(dt, c) for dt, c in imp[:-1] if dt > t_cut] + imp[-1:]
     return rows, full_trace > 0
 
 

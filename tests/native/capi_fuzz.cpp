@@ -1,6 +1,8 @@
 // tests/native/capi_fuzz.cpp -- TEST INFRASTRUCTURE (CPU, no GPU needed).
 // Drives the host side of the C ABI (gnngls_amd/csrc/capi.hip compiled host-only with -fsanitize=address,undefined; the
-// kernel launchers come from the regular libgnngls_hip.so and are never reached by a rejected call) with hostile
+// kernel launchers come from the regular libgnngls_hip.so and are never reached by a rejected call; a call whose shape
+// passes validation is only made with all pointers set when no GPU is visible -- it then fails cleanly inside HIP --
+// and keeps one required pointer NULL when there is one) with hostile
 // arguments: negative / huge B and n, NULL pointers, undersized workspaces, bad enums.  Every call must return an error
 // code with a message (or GNNGLS_OK for an empty batch) -- never crash, never read a data pointer on the host (all
 // data pointers handed in are 1-byte heap blocks, so AddressSanitizer traps any host-side dereference).
@@ -10,6 +12,8 @@
 #include <string.h>
 
 #include "../../include/gnngls_hip.h"
+
+extern "C" int hipGetDeviceCount(int *count);     // libamdhip64 (hipError_t is an int-sized enum; 0 = hipSuccess)
 
 static unsigned long long rng_state = 0x9E3779B97F4A7C15ull;
 static unsigned long long rnd() {
@@ -37,7 +41,8 @@ int main(int argc, char **argv) {
     static const int small[] = {-7, -1, 0, 1, 2, 8, 1 << 20};
     static const int64_t wsb[] = {-1, 0, 1, 255, 256, 4096, 1ll << 40};
     void *blk = malloc(1);                      // stands in for a device pointer: never to be touched on the host
-    int has_device = 0;
+    int device_count = 0;
+    const int has_device = hipGetDeviceCount(&device_count) == 0 && device_count > 0;
     for (int it = 0; it < iters; ++it) {
         void *p[12];
         for (int k = 0; k < 12; ++k) p[k] = (rnd() & 3) ? blk : NULL;

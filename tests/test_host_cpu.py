@@ -134,3 +134,40 @@ def test_synthetic_instances_are_symmetric_euclidean():
     D, pos = random_instances(np.random.default_rng(3), 4, 9)
     assert D.shape == (4, 9, 9) and np.array_equal(D, D.transpose(0, 2, 1)) and (np.diagonal(D, axis1=1, axis2=2) == 0).all()
     assert np.allclose(D[2, 1, 5], np.linalg.norm(pos[2, 1] - pos[2, 5]), rtol=1e-15)
+
+
+def test_cli_progress_rows_always_reach_the_returned_cost():
+    """scripts/test.py progress_rows: whatever the per-move record holds (nothing at all when no move was accepted; a
+    complete record whose minimum is above a never-improved start cost; a truncated one), the rows end on the terminal
+    entry of the improvement record, so the cummin `best_cost` column reaches the returned cost."""
+    import importlib.util
+    import os
+    import types
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gnngls_cli_rows", os.path.join(root, "scripts", "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+
+    def res(moves, trace, imp):
+        r = types.SimpleNamespace()
+        r.moves = torch.tensor([moves])
+        r.trace_time = torch.tensor([[0.1 * (i + 1) for i in range(len(trace))] + [0.0]], dtype=torch.float32)
+        r.trace_cost = torch.tensor([list(trace) + [0.0]], dtype=torch.float64)
+        r.imp_time = torch.tensor([[t for t, _ in imp]], dtype=torch.float32)
+        r.imp_cost = torch.tensor([[c for _, c in imp]], dtype=torch.float64)
+        r.imp_len = torch.tensor([len(imp)])
+        return r
+
+    # no accepted move at all: start tour already locally optimal, budget over after the first descent
+    rows, cut = cli.progress_rows(res(0, [], [(0.0, 7.5), (0.01, 7.5)]), 0, full_trace=100)
+    assert not cut and rows and min(c for _, c in rows) == 7.5
+    # complete record whose costs all lie above the returned best (the best is the cost after the initial descent = start)
+    rows, cut = cli.progress_rows(res(3, [8.0, 7.9, 7.7], [(0.0, 7.5), (1.0, 7.5)]), 0, full_trace=100)
+    assert not cut and len(rows) == 4 and rows[-1][1] == 7.5 and abs(rows[-1][0] - 1.0) < 1e-6
+    # truncated record: improvement events after the cut, then the terminal entry
+    rows, cut = cli.progress_rows(res(9, [8.0, 7.9], [(0.05, 7.9), (0.5, 7.2), (0.9, 7.0), (1.0, 7.0)]), 0, full_trace=2)
+    assert cut and [c for _, c in rows] == [8.0, 7.9, 7.2, 7.0, 7.0]
+    # default record (no per-move trace): improvement events + terminal
+    rows, cut = cli.progress_rows(res(9, [], [(0.05, 7.9), (0.5, 7.2), (1.0, 7.2)]), 0, full_trace=0)
+    assert not cut and [c for _, c in rows] == [7.9, 7.2, 7.2]

@@ -95,6 +95,47 @@ def test_forward_batch_vs_oracle(n, B):
                     f"n={n} b={b}: max |hip - fp32 reference| {err32.max():.3e}"
 
 
+def test_forward_n200_vs_oracle():
+    """BASELINE configs[4] size: ONE TSP200 instance (19,900 line-graph nodes, 7.9 million arcs) through the HIP forward
+    -- the head-split gat_rows_kernel<4> (two workgroups per TSP row, 115 KB tiles) -- against the oracle evaluated in
+    fp64 (arcs from the closed-form rule, aggregation per destination range: tests/test_model_oracle.py pins both to the
+    networkx line graph), 1e-5 relative with the 1e-5 * max|y| floor, no alternative clause."""
+    import copy
+    from gnngls_amd.models import LineGraph
+    from oracle import model_oracle as mo
+    model, oracle, _ = make_models()
+    oracle64 = copy.deepcopy(oracle).double()
+    n = 200
+    N = n * (n - 1) // 2
+    x = torch.from_numpy(np.random.default_rng(n).random((N, 1)).astype(np.float32))
+    with torch.no_grad():
+        y = model(LineGraph(n).to("cuda"), x.cuda()).cpu().numpy().reshape(-1)
+        ref = oracle64(mo.line_graph_arcs_closed_form(n), x.double()).numpy().reshape(-1)
+    assert np.isfinite(y).all() and y.shape == ref.shape
+    assert_regret_close(y, ref)
+
+
+def test_forward_headline_batch_instances_alone_and_vs_oracle():
+    """BASELINE configs[2] shape: 1024 x TSP100 in one call (5.07 million rows, 13.6 GB of workspace).  Instances 0, 511
+    and 1023 of the batch are bit for bit what the same instance gives alone (the instances of a batch do not interact,
+    wherever they sit in the launch grid), and instance 511 matches the fp64 oracle at 1e-5."""
+    import copy
+    from gnngls_amd import models as M
+    from oracle import model_oracle as mo
+    model, oracle, _ = make_models()
+    n, B = 100, 1024
+    N = n * (n - 1) // 2
+    x = torch.from_numpy(np.random.default_rng(1024).random((B * N, 1)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        y = M.regret_forward(model, x, B, n).reshape(B, N)
+        assert torch.isfinite(y).all()
+        for b in (0, 511, 1023):
+            alone = M.regret_forward(model, x[b * N:(b + 1) * N].contiguous(), 1, n).reshape(N)
+            assert torch.equal(alone, y[b]), b
+        ref = copy.deepcopy(oracle).double()(mo.line_graph_arcs_closed_form(n), x[511 * N:512 * N].cpu().double())
+    assert_regret_close(y[511].cpu().numpy(), ref.numpy().reshape(-1))
+
+
 def test_forward_small_workspace_chunks():
     """A workspace that holds one instance at a time gives the same result as the full batch."""
     from gnngls_amd import models as M

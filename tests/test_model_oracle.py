@@ -33,6 +33,23 @@ def test_gat_formulations_agree(n):
     assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [4, 7, 13])
+def test_closed_form_arcs_and_chunked_aggregation(n):
+    """The arc list the large-n GPU tests use (closed-form rule, sorted by destination) is networkx's own line graph,
+    and the destination-range form of the aggregation gives the same bits as the one-shot form."""
+    torch.manual_seed(100 + n)
+    G, C = mo.line_graph_networkx(n), mo.line_graph_arcs_closed_form(n)
+    assert sorted(zip(G.dst.tolist(), G.src.tolist())) == list(zip(C.dst.tolist(), C.src.tolist()))   # sorted by (dst, src)
+    assert torch.equal(C.ndata["e"], G.ndata["e"])
+    N = C.number_of_nodes()
+    ft = torch.randn(N, 8, 16, dtype=torch.float64)
+    el, er = torch.randn(N, 8, dtype=torch.float64) * 3, torch.randn(N, 8, dtype=torch.float64) * 3
+    whole = mo.gat_aggregate_edge_list(ft, el, er, C.src, C.dst)
+    parts = mo._gat_aggregate_chunked(ft, el, er, C.src, C.dst, 0.2, arcs_per_chunk=41)
+    assert torch.equal(whole, parts)
+    assert torch.allclose(whole, mo.gat_aggregate_edge_list(ft, el, er, G.src, G.dst), rtol=1e-13, atol=1e-13)
+
+
 def build_oracle_model():
     g = np.load(os.path.join(GOLD, "model_n5.npz"))
     torch.manual_seed(int(g["model_seed"]))

@@ -73,9 +73,10 @@ def test_solve_batch_start_tour_rule_with_weight_first(model):
     assert differs > 0                                                       # the rule is observable on this batch
 
 
-@pytest.mark.parametrize("n,B,limit", [(50, 128, 1.5), (200, 256, 4.0)])
+@pytest.mark.parametrize("n,B,limit", [(50, 128, 1.5), (100, 1024, 2.0), (200, 256, 4.0)])
 def test_solve_batch_config_sizes_end_to_end(model, n, B, limit):
-    """BASELINE configs[1] (TSP50 x 128: GNN forward + GLS) and configs[4] (TSP200 x 256 per GPU) through the whole
+    """BASELINE configs[1] (TSP50 x 128: GNN forward + GLS), configs[2] (TSP100 x 1024, the headline shape: forward over
+    5.07 million rows, then all 1024 searches resident) and configs[4] (TSP200 x 256 per GPU) through the whole
     pipeline in ONE round: forward, regret guide, start tours, search within the remaining budget; results are valid
     tours with consistent costs, never worse than the start, no aborts, the budget is respected."""
     import time

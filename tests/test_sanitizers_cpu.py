@@ -45,6 +45,7 @@ def test_c_abi_argument_checks_under_asan_ubsan(tmp_path):
                            "-L" + so_dir, "-lgnngls_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + so_dir,
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe] + SAN)
     out = subprocess.run([exe, "60000"], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1"))
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1",
+                                  HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))      # host-side checks only: no GPU
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "capi_fuzz: 60003 calls" in out.stdout and "runtime error" not in out.stderr

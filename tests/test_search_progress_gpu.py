@@ -148,7 +148,8 @@ def _write_dataset(root, n, count, seed):
 
 def test_cli_complete_per_move_record(tmp_path):
     """`--full_trace CAP` with CAP above the number of accepted moves: the rows are the reference's per-move record
-    verbatim (no improvement rows mixed in), and the `best_cost` column still ends on the returned cost."""
+    verbatim plus ONE terminal row (returned best, end of the search; no other improvement rows mixed in), and the
+    `best_cost` column ends on the returned cost."""
     import argparse
     spec = importlib.util.spec_from_file_location("gnngls_cli_test2", os.path.join(ROOT, "scripts", "test.py"))
     cli = importlib.util.module_from_spec(spec)
