@@ -39,6 +39,8 @@ SIGNATURES = {
     "gnngls_debug_set_penalty16_limit": [_int],
     "gnngls_debug_set_stamp_buffer": [_vp],
     "gnngls_debug_set_gls_threads": [_int],
+    "gnngls_debug_set_gls_team": [_int],
+    "gnngls_gls_uses_team": [_int, _int, _int],
     "gnngls_profile_enable": [_int],
     "gnngls_profile_collect": [_vp, _vp],
 }

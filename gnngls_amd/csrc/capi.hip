@@ -57,6 +57,7 @@ struct ProfScope {
 };
 
 int g_pen16_limit = 65535;
+std::atomic<int> g_team_mode{-1};      // -1 = policy (gls_config), 0 = never, 1 = wherever the team form exists (experiments / tests)
 long long *g_stamp_buffer = nullptr;
 
 constexpr size_t kLdsPerCU = 160 * 1024;
@@ -73,9 +74,25 @@ int num_cus() {
 
 // Storage configuration of the persistent search kernel for instances of n nodes: the one with the
 // most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
-struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; };
+struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; bool team = false; };
 
+GlsConfig gls_config_store(int n, int requested_bits, int batch);
+
+// + the form of the perturbation phase: on all wavefronts of the workgroup (team) when every workgroup of the batch gets a
+// CU of its own -- B <= number of CUs: TSP200 x 256 (one 16-wave workgroup per CU by LDS anyway), TSP50 x 128 -- else on
+// wavefront 0 (the CU is shared, the other workgroups' descents fill the SIMDs)
 GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
+    GlsConfig c = gls_config_store(n, requested_bits, batch);
+    const int mode = g_team_mode.load(std::memory_order_relaxed);
+    if (mode != 0 && gnngls::gls_team_supported(c.store, c.penalty_bits, c.wps, n)) {
+        const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, true);
+        const bool own_cu = batch > 0 && batch <= num_cus();
+        if (lds <= kLdsPerCU && (mode == 1 || own_cu)) { c.team = true; c.lds = lds; }
+    }
+    return c;
+}
+
+GlsConfig gls_config_store(int n, int requested_bits, int batch) {
     GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, gnngls::gls_block_threads(n, gnngls::GLS_STORE_GLOBAL),
                    gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0, 4};
     bool have = false, done = false;
@@ -149,6 +166,12 @@ int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *
     if (lds_bytes) *lds_bytes = (int)c.lds;
     if (per_cu) *per_cu = c.store == gnngls::GLS_STORE_GLOBAL ? 0 : c.per_cu;
     return GNNGLS_OK;
+}
+
+int gnngls_gls_uses_team(int n, int B, int penalty_bits) {
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
+        return 0;
+    return gls_config(n, penalty_bits, B).team ? 1 : 0;
 }
 
 int gnngls_two_opt_delta_all(const int32_t *tour, const double *D, int B, int n, double *out, void *stream) {
@@ -242,7 +265,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     hipError_t e;
     {
         ProfScope ps(GNNGLS_PROF_GLS, st);
-        e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, cfg.wps, first_improvement != 0, st);
+        e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, cfg.wps, cfg.team, first_improvement != 0, st);
     }
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
@@ -582,6 +605,12 @@ extern "C" {
 int gnngls_debug_set_penalty16_limit(int limit) {
     if (limit < 1 || limit > 65535) return fail(GNNGLS_ERR_ARG, "penalty16 limit must be in 1..65535");
     g_pen16_limit = limit;
+    return GNNGLS_OK;
+}
+
+int gnngls_debug_set_gls_team(int mode) {
+    if (mode < -1 || mode > 1) return fail(GNNGLS_ERR_ARG, "gls team mode must be -1 (policy), 0 (never) or 1 (wherever it exists)");
+    g_team_mode.store(mode, std::memory_order_relaxed);
     return GNNGLS_OK;
 }
 

@@ -39,13 +39,16 @@ struct GlsArgs {
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
-size_t gls_lds_bytes(int n, int store, int penalty_bits);
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false);
 int gls_block_threads(int n, int store);
 void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 // resident wavefronts per SIMD (= register budget) of the kernel instantiation for this configuration: 4 or 8 for the
 // compact store, fixed for the others
 int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, size_t lds);
-hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool first_improvement,
+// team: perturbation phase on all wavefronts of the workgroup (for workgroups that own their CU); only where
+// gls_team_supported() says so
+bool gls_team_supported(int store, int penalty_bits, int wps, int n);
+hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,

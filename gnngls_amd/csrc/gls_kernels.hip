@@ -847,10 +847,12 @@ __device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n
 // evaluation are issued back to back BEFORE any arithmetic: written through the generic functor the compiler
 // (scheduling for minimum register pressure) emits load -> wait -> use six times in a row, and each wait is a
 // full L1/L2 (penalties) or LDS (distances) round trip on the serial chain of the search.
+// j0 / jstep: the default walks all j = 1 .. n-1 in passes of 64 lanes; the team form of the perturbation phase
+// (team_perturbation below) gives every wavefront ONE pass (j0 = 1 + 64 pass, jstep >= n).
 template <class S, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a_guided(const S &s, double k, const TT *t, int n, int i,
-                                                        int lane, double &bd, int &bk) {
-    for (int j = 1 + lane; j <= n - 1; j += kWave) {
+                                                        int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave) {
+    for (int j = j0 + lane; j <= n - 1; j += jstep) {
         int dj = i - j; if (dj < 0) dj = -dj;
         if (dj < 2) continue;                                // operators.py:61-62
         const int ii = i < j ? i : j, jj = i < j ? j : i;    // operators.py:17-18
@@ -869,7 +871,7 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided(const S &s, double k, co
 
 template <class S, bool FI, class TT>
 __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, const TT *t, int n, int i,
-                                                         int lane, double &bd, int &bk) {
+                                                         int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave) {
     const int a = t[i - 1], b = t[i], c = t[i + 1];
     const int qab = s.idx(a, b), qbc = s.idx(b, c), qac = s.idx(a, c);
     const int pab = s.pen_at(qab), pbc = s.pen_at(qbc), pac = s.pen_at(qac);
@@ -879,7 +881,7 @@ __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, c
     double base = -gab;                                      // operators.py:97-99, left to right
     base = base - gbc;
     base = base + gac;
-    for (int j = 1 + lane; j <= n - 1; j += kWave) {
+    for (int j = j0 + lane; j <= n - 1; j += jstep) {
         if (j == i) continue;                                // operators.py:114-115
         int d, e;
         if (i < j) { d = t[j]; e = t[j + 1]; } else { d = t[j - 1]; e = t[j]; }
@@ -925,6 +927,145 @@ __device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) 
 #pragma unroll 8
     for (int p = 1; p <= n; ++p) c += Ef[p];      // the adds stay in order; the LDS reads of 8 steps overlap
     return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Team form of the perturbation phase (algorithms.py:150-185) for workgroups that own their CU
+// ---------------------------------------------------------------------------------------------
+// The default form runs the phase on wavefront 0 while the other wavefronts of the workgroup park on a barrier: right
+// when the CU is shared by four workgroups (TSP100 x 1024: their descents fill the SIMDs), wasteful when the workgroup
+// has the CU to itself -- TSP200 (159 KB distance triangle, ONE 16-wave workgroup per CU) spends three quarters of an
+// outer iteration in this phase with 15 of 16 wavefronts idle.  Here every wavefront takes part:
+//   * a penalty step's four one-to-all scans (two endpoints x {two_opt_o2a, relocate_o2a}, algorithms.py:167-174) times
+//     their P = ceil((n-1)/64) passes of 64 lanes are 4 P independent UNITS, evaluated concurrently on the current tour
+//     (unit u -> wavefront u mod nwaves); each writes its (delta, j) candidate to an LDS slot; after ONE barrier every
+//     thread reads the slots in the reference's order (endpoint, operator, pass) and finds the first scan with an improving
+//     move.  Scans behind it were speculative: the move changes the tour, so they are evaluated again in the next round
+//     (most scans find no move, so a step usually takes one or two rounds instead of 4 P sequential passes);
+//   * the index of an endpoint is taken once per endpoint on the tour at that moment and reused by relocate_o2a after
+//     two_opt_o2a changed the tour (algorithms.py:169-174) exactly as in the serial form: i of endpoint 0 is the arg-max
+//     position, i of endpoint 1 is looked up at the start of every round in which endpoint 1 has not started yet;
+//   * the utilities of the tour edges (algorithms.py:153-159) are cached by position: wavefront q holds positions
+//     64 q .. 64 q + 63, the partial arg-max of each goes through LDS (first maximum wins: slots are combined in
+//     position order with a strict >), the lane that caches the winning edge stores its incremented counter.
+// Same arithmetic, same candidates, same order of consumption as the serial form: all results stay bit-exact.
+struct TeamCtl {
+    double arg_u[4]; int arg_p[4];       // partial arg-max of the utilities, per block of 64 tour positions
+    double res_d[16]; int res_k[16];     // candidate of unit (scan, pass): scan = 2 endpoint + operator
+    int stop; int pad[3];
+};
+
+template <class S, bool FI, class TT, class TRC>
+__device__ __forceinline__ void team_perturbation(const S &s, const double k, TT *&t, TT *&t2, double *Ef, double *Eb,
+                                                  const int n, TeamCtl *tc, const double *guide, const GlsArgs &A,
+                                                  const long long t_start, const bool eager_cost, double &cur_cost,
+                                                  TRC &tr, long long &evals, int &status, Stamps &st) {
+    static_assert(sizeof(typename S::pen_t) == 4, "team form: 32-bit penalty counters only");
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthr >> 6;
+    const int P = (n - 2 + kWave) / kWave;                   // passes of 64 lanes over j = 1 .. n-1
+    const int units = 4 * P;                                 // n <= 255: at most 16
+    const int NQ = (n + kWave - 1) / kWave;                  // blocks of 64 tour positions 0 .. n-1
+    double gq = 0.0; int pq = 0;                             // utility numerator and penalty of tour edge (p, p+1), p = 64 wave + lane
+    const int myp = wave * kWave + lane;
+    auto reload = [&]() {                                    // asynchronous: consumed by the next arg-max
+        if (wave < NQ && myp < n) { const int u = t[myp], v = t[myp + 1]; gq = guide[(size_t)u * n + v]; pq = s.pen(u, v); }
+    };
+    reload();
+    if (tid == 0) tc->stop = 0;
+    int moves = 0;
+    long long steps = 0;
+    bool any_moved = false;
+    while (moves < A.perturbation_moves) {
+        // ---- arg-max utility over the tour edges, first maximum wins (algorithms.py:153-159) ----
+        if (wave < NQ) {
+            double bu = 0.0; int bp = kNoKey;
+            if (myp < n) { bu = gq / (1.0 + (double)pq); bp = myp; }
+            wave_argmax_first(bu, bp);
+            if (lane == 0) { tc->arg_u[wave] = bu; tc->arg_p[wave] = bp; }
+        }
+        if (tid == 0 && (steps & 63) == 63) {
+            const long long el = wall_clock64() - t_start;
+            if (el > (long long)(A.watchdog_s * 1e8)) tc->stop = 1;
+        }
+        __syncthreads();
+        if (tc->stop) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
+        double bu = tc->arg_u[0]; int bp = tc->arg_p[0];
+        for (int q = 1; q < NQ; ++q) {
+            const double u = tc->arg_u[q];
+            if (u > bu) { bu = u; bp = tc->arg_p[q]; }
+        }
+        STAMP_END(0);
+        const int eu = t[bp], ev = t[bp + 1];
+        if (myp == bp && wave < NQ) { (void)s.pen_set(eu, ev, pq); pq += 1; }       // algorithms.py:161
+        __syncthreads();                                     // the incremented counter is visible to every wavefront's scans
+        bool moved_this_step = false;
+        int s_begin = 0;                                     // first scan (2 endpoint + operator) not consumed yet
+        int i1 = bp + 1;                                     // index of endpoint 1 (algorithms.py:169), see header
+        for (;;) {
+            if (moved_this_step && s_begin <= 2) {           // endpoint 1 not started: cur_tour.index(ev) on the current tour
+                for (int p0 = 0; p0 <= n; p0 += kWave) {
+                    const int p = p0 + lane;
+                    const unsigned long long m = __ballot(p <= n && t[p] == ev);
+                    if (m) { i1 = p0 + __ffsll((long long)m) - 1; break; }
+                }
+            }
+            for (int unit = wave; unit < units; unit += nwaves) {
+                const int sc = unit / P, pass = unit - sc * P;
+                const int node = sc >= 2 ? ev : eu;
+                double bd = 0.0; int bk = kNoKey;
+                if (sc >= s_begin && node != 0) {            // algorithms.py:168
+                    const int i = sc >= 2 ? i1 : bp;
+                    if ((sc & 1) == 0) scan_two_opt_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n);
+                    else               scan_relocate_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n);
+                    if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
+                }
+                if (lane == 0) { tc->res_d[unit] = bd; tc->res_k[unit] = bk; }
+            }
+            STAMP_END(1);
+            __syncthreads();
+            // consume in the reference's order: endpoint, operator; inside a scan the passes ascend in j
+            int found = -1, fk = kNoKey;
+            for (int sc = s_begin; sc < 4 && found < 0; ++sc) {
+                if ((sc >= 2 ? ev : eu) == 0) continue;
+                double bd = 0.0; int bk = kNoKey;
+                for (int pass = 0; pass < P; ++pass) {
+                    const int ok = tc->res_k[sc * P + pass];
+                    if (ok == kNoKey) continue;
+                    const double od = tc->res_d[sc * P + pass];
+                    if (bk == kNoKey || better<FI>(od, ok, bd, bk)) { bd = od; bk = ok; }
+                }
+                if (tid == 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
+                if (bk != kNoKey) { found = sc; fk = bk; }
+            }
+            STAMP_END(2);
+            if (found < 0) break;
+            apply_move(s, t, t2, Ef, Eb, n, found & 1, found >= 2 ? i1 : bp, fk, tid, nthr, eager_cost);   // algorithms.py:175-177
+            { TT *x = t; t = t2; t2 = x; }
+            __syncthreads();                                 // also orders this round's slot reads before the next round's writes
+            any_moved = true; moved_this_step = true;
+            moves += 1;                                      // algorithms.py:185
+            reload();
+            if (eager_cost) {
+                cur_cost = tour_cost_from_edges(Ef, n);      // algorithms.py:176 (every thread: the value stays uniform)
+                if (tid == 0) tr.push(cur_cost);
+            } else if (tid == 0) {
+                tr.len++;                                    // move counted, cost deferred
+            }
+            STAMP_END(3);
+            s_begin = found + 1;
+            if (s_begin >= 4) break;
+        }
+        steps++;
+        STAMP_COUNT(6);
+    }
+    if (any_moved && !eager_cost) {
+        build_edges(s, t, Ef, Eb, n, tid, nthr);
+        __syncthreads();
+        cur_cost = tour_cost_from_edges(Ef, n);
+    }
+    STAMP_END(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1007,7 +1148,8 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
 // WPS = resident wavefronts per SIMD the kernel is compiled for = its register budget (512 / WPS VGPRs).  The compact store
 // exists twice: WPS 4 (128 VGPRs, no spills: the instantiation a full TSP100 device load runs on, four 4-wave workgroups
 // per CU) and WPS 8 (64 VGPRs, ~100 B of scratch) for batches of small instances that need more than 16 waves per CU.
-template <class S, bool FI, int GP, bool TR, int WPS>
+// TEAM: the perturbation phase runs on all wavefronts (team_perturbation above) -- for workgroups that own their CU.
+template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM = false>
 __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -1020,6 +1162,8 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     // ---- LDS carve (all offsets multiples of 16) ----
     size_t off = 0;
     Ctl *ctl = reinterpret_cast<Ctl *>(smem + off);            off += (sizeof(Ctl) + 15) & ~size_t(15);
+    TeamCtl *tc = nullptr;
+    if constexpr (TEAM) { tc = reinterpret_cast<TeamCtl *>(smem + off); off += (sizeof(TeamCtl) + 15) & ~size_t(15); }
     double *Ef = reinterpret_cast<double *>(smem + off);       off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15);
     double *Eb = Ef;
     if (!S::kSymmetric) { Eb = reinterpret_cast<double *>(smem + off); off += ((size_t)(n + 2) * 8 + 15) & ~size_t(15); }
@@ -1112,7 +1256,11 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         if (!ctl->flag) break;
         const double *guide = A.guides + ((size_t)(iter_i % A.n_guides) * A.B + b) * nn;   // algorithms.py:147
 
-        // ---- perturbation (algorithms.py:150-185): wavefront 0 only ----
+        // ---- perturbation (algorithms.py:150-185): all wavefronts (TEAM) or wavefront 0 only ----
+        if constexpr (TEAM) {
+            STAMP_BEGIN();
+            team_perturbation<S, FI>(s, k, t, t2, Ef, Eb, n, tc, guide, A, t_start, eager_cost, cur_cost, tr, evals, status, st);
+        } else {
         if (wave == 0) {
             STAMP_BEGIN();
             // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
@@ -1235,6 +1383,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             TT *cur = reinterpret_cast<TT *>(smem + ctl->pad);
             if (cur != t) { TT *x = t; t = t2; t2 = x; }
             cur_cost = ctl->cost;
+        }
         }
 
         // ---- optimisation (algorithms.py:188) ----
@@ -1393,10 +1542,11 @@ __global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------------------
-size_t gls_lds_bytes(int n, int store, int penalty_bits) {
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team) {
     auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t tour_elem = store == GLS_STORE_COMPACT ? 1 : 4;
     size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * tour_elem);
+    if (team) off += r16(sizeof(TeamCtl));
     if (store == GLS_STORE_GLOBAL) off += r16((size_t)(n + 2) * 8);
     size_t ntri = (size_t)n * (n - 1) / 2;
     if (store != GLS_STORE_GLOBAL) off += r16(ntri * 8);
@@ -1442,9 +1592,9 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
     return (batch > 0 && (long)per_cu4 * num_cus < batch && 32 / waves > per_cu4 && by_lds > per_cu4) ? 8 : 4;
 }
 
-template <class S, bool FI, int GP, bool TR, int WPS>
+template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM>
 static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    auto kern = gls_kernel<S, FI, GP, TR, WPS>;
+    auto kern = gls_kernel<S, FI, GP, TR, WPS, TEAM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1453,37 +1603,47 @@ static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStr
     return hipGetLastError();
 }
 
-template <class S, bool FI, int GP, int WPS>
+template <class S, bool FI, int GP, int WPS, bool TEAM>
 static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
     // trace_cap == 0 (no trace buffer): the trace-free instantiation (fewer live registers in the serial phase)
-    if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true, WPS>(A, lds, threads, stream);
-    return launch_gls_k<S, FI, GP, false, WPS>(A, lds, threads, stream);
+    if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true, WPS, TEAM>(A, lds, threads, stream);
+    return launch_gls_k<S, FI, GP, false, WPS, TEAM>(A, lds, threads, stream);
 }
 
-template <class S, bool FI, int WPS>
+template <class S, bool FI, int WPS, bool TEAM>
 static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
     // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover positions 0..n for n <= 127
-    if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2, WPS>(A, lds, threads, stream);
-    return launch_gls_g<S, FI, kGuidePassesMax, WPS>(A, lds, threads, stream);
+    if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2, WPS, TEAM>(A, lds, threads, stream);
+    return launch_gls_g<S, FI, kGuidePassesMax, WPS, TEAM>(A, lds, threads, stream);
 }
 
-template <class S, int WPS>
+template <class S, int WPS, bool TEAM = false>
 static hipError_t launch_gls_f(const GlsArgs &A, size_t lds, int threads, bool first_improvement, hipStream_t stream) {
-    return first_improvement ? launch_gls_t<S, true, WPS>(A, lds, threads, stream)
-                             : launch_gls_t<S, false, WPS>(A, lds, threads, stream);
+    return first_improvement ? launch_gls_t<S, true, WPS, TEAM>(A, lds, threads, stream)
+                             : launch_gls_t<S, false, WPS, TEAM>(A, lds, threads, stream);
 }
 
-hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool first_improvement,
+bool gls_team_supported(int store, int penalty_bits, int wps, int n) {
+    // the team form exists for the 128-VGPR builds of the two symmetric stores with 32-bit counters, n <= 255
+    return (store == GLS_STORE_COMPACT || (store == GLS_STORE_TRI && penalty_bits == 32)) && wps == 4 && n >= 4 && n <= 255;
+}
+
+hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream) {
-    size_t lds = gls_lds_bytes(A.n, store, penalty_bits);
-    if (store == GLS_STORE_COMPACT)
+    if (team && !gls_team_supported(store, penalty_bits, wps, A.n)) return hipErrorInvalidValue;
+    size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
+    if (store == GLS_STORE_COMPACT) {
+        if (team) return launch_gls_f<TriDGlobalP, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)
                         : launch_gls_f<TriDGlobalP, 4>(A, lds, threads, first_improvement, stream);
+    }
     if (store == GLS_STORE_TRI && penalty_bits == 16)
         return launch_gls_f<TriStore<uint16_t>, TriStore<uint16_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
-    if (store == GLS_STORE_TRI)
+    if (store == GLS_STORE_TRI) {
+        if (team) return launch_gls_f<TriStore<int32_t>, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 4 ? launch_gls_f<TriStore<int32_t>, 4>(A, lds, threads, first_improvement, stream)
                         : launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+    }
     return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
 }
 

@@ -182,11 +182,29 @@ def gls_resident_capacity(n):
     return _lib.load().gnngls_gls_resident_capacity(int(n))
 
 
+class gls_team_mode:
+    """Experiment / test hook (gnngls_debug_set_gls_team): `with gls_team_mode(1): ...` runs gls_run with the team form of
+    the perturbation phase wherever it exists, 0 never, -1 = the library's policy (B <= number of CUs).  Results are
+    bit-identical either way."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        _lib.check(_lib.load().gnngls_debug_set_gls_team(self.mode), "debug_set_gls_team")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.load().gnngls_debug_set_gls_team(-1), "debug_set_gls_team")
+        return False
+
+
 def gls_describe_config(n, B=0, penalty_bits=0):
-    """-> dict(store, threads, lds_bytes, per_cu): what gnngls_gls_run would use (host-side query)."""
+    """-> dict(store, threads, lds_bytes, per_cu, team): what gnngls_gls_run would use (host-side query)."""
     vals = [ctypes.c_int(0) for _ in range(4)]
     _lib.check(_lib.load().gnngls_gls_describe_config(int(n), int(B), int(penalty_bits),
                                                       *[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals]),
                "gls_describe_config")
     names = {0: "global", 116: "lds-tri-u16", 132: "lds-tri-i32", 200: "compact"}
-    return {"store": names[vals[0].value], "threads": vals[1].value, "lds_bytes": vals[2].value, "per_cu": vals[3].value}
+    return {"store": names[vals[0].value], "threads": vals[1].value, "lds_bytes": vals[2].value, "per_cu": vals[3].value,
+            "team": bool(_lib.load().gnngls_gls_uses_team(int(n), int(B), int(penalty_bits)))}

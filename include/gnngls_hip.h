@@ -191,6 +191,16 @@ int gnngls_debug_set_penalty16_limit(int limit);
  * instance size).  Used by scripts/probe_gls.py to measure the policy; never called by the product. */
 int gnngls_debug_set_gls_threads(int threads);
 
+/* 1 if gnngls_gls_run would run the perturbation phase of this (n, B, penalty_bits) on ALL wavefronts of the workgroup
+ * (the "team" form: the four one-to-all scans of a penalty step, algorithms.py:167-174, evaluated concurrently and consumed
+ * in the reference's order -- chosen when every workgroup of the batch owns a CU, B <= number of CUs), 0 if on wavefront 0
+ * only.  Same results either way (bit-exact); this only reports the policy. */
+int gnngls_gls_uses_team(int n, int B, int penalty_bits);
+
+/* Experiment / test hook: -1 = the policy above (default), 0 = never use the team form, 1 = use it wherever it exists
+ * (symmetric stores with 32-bit counters, n <= 255) whatever the batch size.  Never called by the product. */
+int gnngls_debug_set_gls_team(int mode);
+
 /* Diagnostic hook: device buffer of 16 int64 per instance that a library built with -DGLS_STAMPS fills with
  * per-phase shader-cycle totals of gnngls_gls_run (scripts/probe_gls_stamps.py).  Ignored by normal builds. */
 int gnngls_debug_set_stamp_buffer(void *device_buffer);

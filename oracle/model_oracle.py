@@ -164,11 +164,13 @@ _CHUNK_ELEMS = 1 << 28       # [E,H,F] temporaries above this many elements (2 G
 
 def _gat_aggregate_chunked(ft, el, er, src, dst, slope, arcs_per_chunk=1 << 20):
     """gat_aggregate_edge_list for graphs whose [E,H,F] message tensor does not fit in memory (K_200: 7.9 million arcs x
-    128 features): the same formulas on consecutive destination ranges.  Needs arcs sorted by destination (every
-    destination's in-arcs then sit in one range, in their original order, so each range is the unchunked computation
-    restricted to those destinations)."""
+    128 features): the same formulas on consecutive destination ranges.  Arcs are brought into destination order first
+    (stable: every destination's in-arcs keep their original order and sit in one range, so each range is the unchunked
+    computation restricted to those destinations)."""
     N, H, F = ft.shape
-    assert bool((dst[1:] >= dst[:-1]).all()), "chunked aggregation needs arcs sorted by destination"
+    if not bool((dst[1:] >= dst[:-1]).all()):
+        order = torch.sort(dst, stable=True).indices
+        src, dst = src[order], dst[order]
     out = torch.zeros((N, H, F), dtype=ft.dtype)
     E, a = src.numel(), 0
     while a < E:

@@ -16,8 +16,10 @@ tl = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
 bits = int(sys.argv[4]) if len(sys.argv) > 4 else 0              # penalty_bits: 0 auto, -2 compact store, 32 / 16 LDS counters
 guide_kind = sys.argv[5] if len(sys.argv) > 5 else "weight"      # weight | noise (clamped fp32 noise, like an untrained model)
 threads = int(sys.argv[6]) if len(sys.argv) > 6 else 0           # workgroup size override (0 = default policy)
+team = int(sys.argv[7]) if len(sys.argv) > 7 else -1             # perturbation phase: -1 policy, 0 wavefront 0, 1 all wavefronts
 from gnngls_amd import _lib  # noqa: E402
 _lib.check(_lib.load().gnngls_debug_set_gls_threads(threads))
+_lib.check(_lib.load().gnngls_debug_set_gls_team(team))
 print("capacity", ops.gls_resident_capacity(n), ops.gls_describe_config(n, Bs[0], bits))
 for B in Bs:
     D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()
@@ -37,6 +39,6 @@ for B in Bs:
     torch.cuda.synchronize()
     dt = time.time() - t0
     it = r.outer_iters.double()
-    print(f"n={n} B={B} bits={bits} thr={threads} guide={guide_kind} wall={dt:.2f}s outer_iters mean={it.mean():.0f} min={it.min():.0f} "
+    print(f"n={n} B={B} bits={bits} thr={threads} team={team} guide={guide_kind} wall={dt:.2f}s outer_iters mean={it.mean():.0f} min={it.min():.0f} "
           f"evals/s={r.evals.sum().item() / dt:.3e} moves mean={r.trace_len.double().mean():.0f} "
           f"init={cost.mean():.4f} best={r.best_cost.mean():.4f} status={r.status.sum().item()}")

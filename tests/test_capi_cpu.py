@@ -90,13 +90,18 @@ def test_gls_store_selection(lib):
     4-wave workgroups on the 128-VGPR build)."""
     from gnngls_amd import ops
     c = ops.gls_describe_config(100, 1024)
-    assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4}
+    assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4, "team": False}
+    # perturbation phase on all wavefronts only where every workgroup of the batch owns a CU (B <= 256 CUs)
+    t200 = ops.gls_describe_config(200, 256)
+    assert t200["store"] == "compact" and t200["team"] and t200["threads"] == 1024 and t200["lds_bytes"] <= 160 * 1024
+    assert not ops.gls_describe_config(200, 257)["team"] and ops.gls_describe_config(50, 128)["team"]
+    assert not ops.gls_describe_config(100, 128, penalty_bits=16)["team"] and not ops.gls_describe_config(300, 8)["team"]
     assert ops.gls_resident_capacity(100) == 1024 and ops.gls_resident_capacity(50) == 2048
     assert ops.gls_describe_config(50, 1024)["per_cu"] >= 4 and ops.gls_describe_config(50, 2048)["per_cu"] == 8
     assert ops.gls_describe_config(20, 1000)["threads"] == 64 and ops.gls_describe_config(20, 1000)["per_cu"] >= 4
     assert ops.gls_describe_config(100, 512)["store"] == "lds-tri-i32" and ops.gls_describe_config(100, 512)["per_cu"] == 2
     assert ops.gls_describe_config(100, 513)["store"] == "compact"            # 16-bit LDS counters only on request
-    assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3}
+    assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3, "team": False}
     assert ops.gls_describe_config(200, 256)["store"] == "compact" and ops.gls_describe_config(200, 256)["per_cu"] == 1
     assert ops.gls_describe_config(300, 8)["store"] == "global"
     assert 4 * ops.gls_describe_config(100, 1024)["lds_bytes"] == 160 * 1024

@@ -42,10 +42,15 @@ for _ in range(14):
                       bits=int(_rng2.choice([0, -2])), guides=int(_rng2.integers(1, 3)), seed=int(_rng2.integers(1 << 30))))
 
 
+@pytest.mark.parametrize("team", [0, 1], ids=["serial", "team"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: f"n{c['n']}-{c['kind']}-pm{c['pm']}-fi{int(c['fi'])}-K{c['K']}-b{c['bits']}-g{c['guides']}")
-def test_fuzz_case(c):
+def test_fuzz_case(c, team):
+    """team: the form of the perturbation phase -- 0 = on wavefront 0 (what a device-filling batch runs), 1 = on all
+    wavefronts of the workgroup wherever that form exists (what the policy picks when B <= number of CUs)."""
     from gnngls_amd import ops
     from oracle import gls_oracle as go
+    if team and c["bits"] == 16:
+        pytest.skip("the team form exists for 32-bit counters only: same kernel as the serial case")
     rng = np.random.default_rng(c["seed"])
     n, B = c["n"], 3
     Ds, Gs = zip(*[make_case(rng, n, c["kind"]) for _ in range(B)])
@@ -55,8 +60,15 @@ def test_fuzz_case(c):
     gd = torch.from_numpy(np.ascontiguousarray(guides)).cuda()
     init = ops.nearest_neighbor(gd[0].contiguous())
     cost = ops.tour_cost(init, d)
-    r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
-                    trace_cap=1 << 13, want_penalty=True, penalty_bits=c["bits"])
+    with ops.gls_team_mode(team):
+        assert ops.gls_describe_config(n, B, c["bits"])["team"] == bool(team)
+        r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
+                        trace_cap=1 << 13, want_penalty=True, penalty_bits=c["bits"])
+        if team:                                                 # and the trace-free instantiation of the same form
+            plain = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"],
+                                max_outer_iters=c["K"], penalty_bits=c["bits"])
+            assert torch.equal(plain.best_tour, r.best_tour) and torch.equal(plain.best_cost, r.best_cost)
+            assert torch.equal(plain.trace_len, r.trace_len) and torch.equal(plain.evals, r.evals)
     init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
     for b in range(B):
         assert init_h[b].tolist() == go.nearest_neighbor(guides[0, b])

@@ -120,9 +120,11 @@ def test_misc_golden(ops):
     assert_bits(c.cpu().numpy()[0], g["tc_cost"])
 
 
+@pytest.mark.parametrize("team", [0, 1], ids=["serial", "team"])
 @pytest.mark.parametrize("n,B,K", [(7, 16, 6), (20, 32, 10), (33, 16, 6), (64, 8, 4), (65, 8, 4), (100, 16, 3), (130, 4, 2)])
-def test_gls_batch_vs_oracle(ops, n, B, K):
-    """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup."""
+def test_gls_batch_vs_oracle(ops, n, B, K, team):
+    """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup; perturbation phase on wavefront 0
+    (serial) and on all wavefronts of the workgroup (team)."""
     from oracle import gls_oracle as go
     rng = np.random.default_rng(1000 + n)
     D, _ = random_instances(rng, B, n)
@@ -133,7 +135,9 @@ def test_gls_batch_vs_oracle(ops, n, B, K):
     d, gd = dev(D, torch.float64), dev(guides, torch.float64)
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
-    r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=1 << 14, want_penalty=True)
+    with ops.gls_team_mode(team):
+        assert ops.gls_describe_config(n, B)["team"] == bool(team)
+        r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=1 << 14, want_penalty=True)
     init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
     for b in range(B):
         assert init_h[b].tolist() == go.nearest_neighbor(guide[b])
@@ -152,7 +156,8 @@ def test_gls_batch_vs_oracle(ops, n, B, K):
     (131, 3, 2, -2, "compact", 2), (131, 3, 2, 0, "lds-tri-i32", 1), (160, 3, 2, -2, "compact", 1),
     (160, 3, 2, 0, "lds-tri-i32", 1), (200, 3, 2, 0, "compact", 1), (200, 2, 1, -2, "compact", 1)])
 @pytest.mark.parametrize("fi", [False, True])
-def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi):
+@pytest.mark.parametrize("team", [0, -1], ids=["serial", "policy"])
+def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi, team):
     """BASELINE configs[4] regime (TSP200; n = 131..200): one or two workgroups per CU (up to 159 KB of LDS for the
     distance triangle), no row-on-the-lane descent (n - 1 > 128), four register passes of cached utilities -- on the
     store gnngls_gls_run picks by itself and on the compact store (the one TSP200 x 256 runs on).  Two guides, both
@@ -161,7 +166,9 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi)
     from oracle import gls_oracle as go
     cfg = ops.gls_describe_config(n, B, penalty_bits=bits)
     assert cfg["store"] == store and cfg["per_cu"] == per_cu and cfg["lds_bytes"] > 64 * 1024, cfg
-    assert ops.gls_describe_config(200, 256)["store"] == "compact"
+    assert cfg["team"]                                       # B <= number of CUs: the policy picks the team form
+    c200 = ops.gls_describe_config(200, 256)
+    assert c200["store"] == "compact" and c200["team"] and c200["threads"] == 1024 and c200["lds_bytes"] <= 160 * 1024
     rng = np.random.default_rng(4000 + n)
     D, _ = random_instances(rng, B, n)
     guide = np.maximum(rng.normal(0.05, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)
@@ -171,10 +178,12 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi)
     d, gd = dev(D, torch.float64), dev(guides, torch.float64)
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
-    r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
-                    trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
-    plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
-                        penalty_bits=bits)                                                                  # no-trace kernel
+    with ops.gls_team_mode(team):
+        assert ops.gls_describe_config(n, B, penalty_bits=bits)["team"] == (team != 0)
+        r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
+                        trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
+        plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
+                            penalty_bits=bits)                                                              # no-trace kernel
     init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
     for b in range(B):
         assert init_h[b].tolist() == go.nearest_neighbor(guide[b])

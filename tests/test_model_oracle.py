@@ -48,6 +48,9 @@ def test_closed_form_arcs_and_chunked_aggregation(n):
     parts = mo._gat_aggregate_chunked(ft, el, er, C.src, C.dst, 0.2, arcs_per_chunk=41)
     assert torch.equal(whole, parts)
     assert torch.allclose(whole, mo.gat_aggregate_edge_list(ft, el, er, G.src, G.dst), rtol=1e-13, atol=1e-13)
+    # arcs in networkx's own (unsorted) order: brought into destination order first, same bits as the one-shot form
+    assert torch.equal(mo._gat_aggregate_chunked(ft, el, er, G.src, G.dst, 0.2, arcs_per_chunk=29),
+                       mo.gat_aggregate_edge_list(ft, el, er, G.src, G.dst))
 
 
 def build_oracle_model():
