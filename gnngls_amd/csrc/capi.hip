@@ -86,8 +86,10 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
     const int mode = g_team_mode.load(std::memory_order_relaxed);
     if (mode != 0 && gnngls::gls_team_supported(c.store, c.penalty_bits, c.wps, n)) {
         const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, true);
-        const bool own_cu = batch > 0 && batch <= num_cus();
-        if (lds <= kLdsPerCU && (mode == 1 || own_cu)) { c.team = true; c.lds = lds; }
+        // ... and a one-to-all scan has at least two passes of 64 lanes to share out (n >= 66): with one pass per scan a
+        // round of the team form costs what the four serial scans cost (TSP50 x 128: 18.3k vs 21.2k iterations in 2 s)
+        const bool pays = batch > 0 && batch <= num_cus() && n - 1 > 64;
+        if (lds <= kLdsPerCU && (mode == 1 || pays)) { c.team = true; c.lds = lds; }
     }
     return c;
 }
@@ -254,7 +256,8 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
         // penalties in global memory (zeroed workspace): full matrices for the global store, packed
         // triangles for the compact store
         // global store: int32 [n,n] per instance; compact store: int32 packed triangle
-        size_t per = cfg.store == gnngls::GLS_STORE_GLOBAL ? (size_t)n * n : (size_t)n * (n - 1) / 2;
+        // (the team form of the compact store keeps a full symmetric matrix too: row-contiguous reads, see TriDGlobalPF)
+        size_t per = (cfg.store == gnngls::GLS_STORE_GLOBAL || cfg.team) ? (size_t)n * n : (size_t)n * (n - 1) / 2;
         size_t bytes = (size_t)B * per * sizeof(int32_t);
         hipError_t e = hipMallocAsync((void **)&ws, bytes, st);
         if (e != hipSuccess) return hip_fail(e, "gls_run: workspace alloc");

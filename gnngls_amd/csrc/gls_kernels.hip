@@ -161,6 +161,24 @@ struct TriDGlobalP {
     }
 };
 
+// The compact store as the TEAM form of the perturbation phase uses it (one workgroup per CU, all wavefronts scan at
+// once): the counters are a full symmetric n x n matrix in global memory, not a packed triangle.  A scan reads
+// P[u, t[j]] with u wave-uniform, so the 64 lanes of a load fall into the 4n bytes of row u -- a handful of cache lines
+// instead of 64: sixteen wavefronts issuing scattered triangle loads at once were bound by the address path of the CU
+// (~3.5k cycles per round waiting for the slowest wavefront, profiles/r03_team_*.log).  Both orientations of a pair are
+// stored (two stores per penalty step, by the one lane that owns the edge).
+struct TriDGlobalPF : TriDGlobalP {
+    int n;
+    __device__ __forceinline__ int pen(int a, int b) const { return p[a * n + b]; }
+    __device__ __forceinline__ bool pen_inc(int a, int b) const { p[a * n + b] += 1; p[b * n + a] += 1; return false; }
+    __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {
+        p[a * n + b] = old_count + 1; p[b * n + a] = old_count + 1;
+        return false;
+    }
+};
+template <class S> struct PenRowMajor { static constexpr bool value = false; };
+template <> struct PenRowMajor<TriDGlobalPF> { static constexpr bool value = true; };
+
 // Full row-major matrices in global memory (any n, asymmetric D allowed: index order follows the
 // reference exactly).  Used when the triangles do not fit in LDS and by the unit kernels.
 struct GlobalStore {
@@ -849,17 +867,21 @@ __device__ __forceinline__ void scan_relocate_o2a(const TT *t, const F &f, int n
 // full L1/L2 (penalties) or LDS (distances) round trip on the serial chain of the search.
 // j0 / jstep: the default walks all j = 1 .. n-1 in passes of 64 lanes; the team form of the perturbation phase
 // (team_perturbation below) gives every wavefront ONE pass (j0 = 1 + 64 pass, jstep >= n).
-template <class S, bool FI, class TT>
+// KNOWN (team form): the counter at packed index qk is pk whatever the load returns -- the edge a penalty step has just
+// incremented, whose store by another wavefront may or may not have landed yet.
+template <class S, bool FI, class TT, bool KNOWN = false>
 __device__ __forceinline__ void scan_two_opt_o2a_guided(const S &s, double k, const TT *t, int n, int i,
-                                                        int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave) {
+                                                        int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave,
+                                                        int qk = -1, int pk = 0) {
     for (int j = j0 + lane; j <= n - 1; j += jstep) {
         int dj = i - j; if (dj < 0) dj = -dj;
         if (dj < 2) continue;                                // operators.py:61-62
         const int ii = i < j ? i : j, jj = i < j ? j : i;    // operators.py:17-18
         const int a = t[ii], b = t[ii - 1], c = t[jj], d = t[jj - 1];
         const int q0 = s.idx(a, c), q1 = s.idx(b, d), q2 = s.idx(a, b), q3 = s.idx(c, d);
-        const int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2), p3 = s.pen_at(q3);
+        int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2), p3 = s.pen_at(q3);
         const double d0 = s.dist_at(q0), d1 = s.dist_at(q1), d2 = s.dist_at(q2), d3 = s.dist_at(q3);
+        if constexpr (KNOWN) { p0 = q0 == qk ? pk : p0; p1 = q1 == qk ? pk : p1; p2 = q2 == qk ? pk : p2; p3 = q3 == qk ? pk : p3; }
         const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
         const double g2 = d2 + k * (double)p2, g3 = d3 + k * (double)p3;
         double delta = g0 + g1;                              // operators.py:25-28, left to right
@@ -869,12 +891,14 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided(const S &s, double k, co
     }
 }
 
-template <class S, bool FI, class TT>
+template <class S, bool FI, class TT, bool KNOWN = false>
 __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, const TT *t, int n, int i,
-                                                         int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave) {
+                                                         int lane, double &bd, int &bk, int j0 = 1, int jstep = kWave,
+                                                         int qk = -1, int pk = 0) {
     const int a = t[i - 1], b = t[i], c = t[i + 1];
     const int qab = s.idx(a, b), qbc = s.idx(b, c), qac = s.idx(a, c);
-    const int pab = s.pen_at(qab), pbc = s.pen_at(qbc), pac = s.pen_at(qac);
+    int pab = s.pen_at(qab), pbc = s.pen_at(qbc), pac = s.pen_at(qac);
+    if constexpr (KNOWN) { pab = qab == qk ? pk : pab; pbc = qbc == qk ? pk : pbc; pac = qac == qk ? pk : pac; }
     const double gab = s.dist_at(qab) + k * (double)pab;
     const double gbc = s.dist_at(qbc) + k * (double)pbc;
     const double gac = s.dist_at(qac) + k * (double)pac;
@@ -886,8 +910,9 @@ __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, c
         int d, e;
         if (i < j) { d = t[j]; e = t[j + 1]; } else { d = t[j - 1]; e = t[j]; }
         const int q0 = s.idx(d, e), q1 = s.idx(d, b), q2 = s.idx(b, e);
-        const int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2);
+        int p0 = s.pen_at(q0), p1 = s.pen_at(q1), p2 = s.pen_at(q2);
         const double d0 = s.dist_at(q0), d1 = s.dist_at(q1), d2 = s.dist_at(q2);
+        if constexpr (KNOWN) { p0 = q0 == qk ? pk : p0; p1 = q1 == qk ? pk : p1; p2 = q2 == qk ? pk : p2; }
         const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1, g2 = d2 + k * (double)p2;
         double delta = base - g0;                            // operators.py:100-102
         delta = delta + g1;
@@ -929,6 +954,59 @@ __device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) 
     return c;
 }
 
+// One pass (j = j0 + lane) of the guided one-to-all scans for the row-major penalty matrix of TriDGlobalPF: same operands,
+// same arithmetic as scan_*_o2a_guided; a counter is read at [wave-uniform node][the lane's node] wherever the pair has a
+// wave-uniform node.  (qk1, qk2) are the two matrix cells of the edge this penalty step incremented, pk its new count.
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k, const TT *t, int n, int i, int j,
+                                                           int qk1, int qk2, int pk, double &bd, int &bk) {
+    int dj = i - j; if (dj < 0) dj = -dj;
+    if (j > n - 1 || dj < 2) return;                         // operators.py:61-62
+    const bool lt = i < j;
+    const int ii = lt ? i : j, jj = lt ? j : i;              // operators.py:17-18
+    const int a = t[ii], b = t[ii - 1], c = t[jj], d = t[jj - 1];
+    const int r0 = lt ? a * n + c : c * n + a;               // {a,c}: row of t[i]
+    const int r1 = lt ? b * n + d : d * n + b;               // {b,d}: row of t[i-1]
+    const int r2 = a * n + b, r3 = c * n + d;                // the two tour edges (one of them wave-uniform)
+    int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2], p3 = s.p[r3];
+    const double d0 = s.dist(a, c), d1 = s.dist(b, d), d2 = s.dist(a, b), d3 = s.dist(c, d);
+    p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1;
+    p2 = (r2 == qk1 || r2 == qk2) ? pk : p2; p3 = (r3 == qk1 || r3 == qk2) ? pk : p3;
+    const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
+    const double g2 = d2 + k * (double)p2, g3 = d3 + k * (double)p3;
+    double delta = g0 + g1;                                  // operators.py:25-28, left to right
+    delta = delta - g2;
+    delta = delta - g3;
+    consider<FI>(delta, j, bd, bk);
+}
+
+template <class S, bool FI, class TT>
+__device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k, const TT *t, int n, int i, int j,
+                                                            int qk1, int qk2, int pk, double &bd, int &bk) {
+    const int a = t[i - 1], b = t[i], c = t[i + 1];
+    const int rab = b * n + a, rbc = b * n + c, rac = a * n + c;
+    int pab = s.p[rab], pbc = s.p[rbc], pac = s.p[rac];
+    const bool live = j <= n - 1 && j != i;                  // operators.py:114-115
+    const int jc = live ? j : (i == 1 ? 2 : 1);
+    int d, e;
+    if (i < jc) { d = t[jc]; e = t[jc + 1]; } else { d = t[jc - 1]; e = t[jc]; }
+    const int r0 = d * n + e, r1 = b * n + d, r2 = b * n + e;        // {d,e}: the lane's tour edge; {d,b}, {b,e}: row of b
+    int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2];
+    const double dab = s.dist(a, b), dbc = s.dist(b, c), dac = s.dist(a, c);
+    const double d0 = s.dist(d, e), d1 = s.dist(d, b), d2 = s.dist(b, e);
+    pab = (rab == qk1 || rab == qk2) ? pk : pab; pbc = (rbc == qk1 || rbc == qk2) ? pk : pbc; pac = (rac == qk1 || rac == qk2) ? pk : pac;
+    p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1; p2 = (r2 == qk1 || r2 == qk2) ? pk : p2;
+    const double gab = dab + k * (double)pab, gbc = dbc + k * (double)pbc, gac = dac + k * (double)pac;
+    double base = -gab;                                      // operators.py:97-99, left to right
+    base = base - gbc;
+    base = base + gac;
+    const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1, g2 = d2 + k * (double)p2;
+    double delta = base - g0;                                // operators.py:100-102
+    delta = delta + g1;
+    delta = delta + g2;
+    if (live) consider<FI>(delta, j, bd, bk);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Team form of the perturbation phase (algorithms.py:150-185) for workgroups that own their CU
 // ---------------------------------------------------------------------------------------------
@@ -951,9 +1029,14 @@ __device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) 
 // Same arithmetic, same candidates, same order of consumption as the serial form: all results stay bit-exact.
 struct TeamCtl {
     double arg_u[4]; int arg_p[4];       // partial arg-max of the utilities, per block of 64 tour positions
+    int arg_c[4];                        // penalty counter of that block's arg-max edge
     double res_d[16]; int res_k[16];     // candidate of unit (scan, pass): scan = 2 endpoint + operator
     int stop; int pad[3];
 };
+
+// Workgroup barrier that orders LDS accesses only: global loads in flight (the asynchronous reloads of the cached
+// utilities after a move: guide matrix entries from L2 / HBM) keep flying, where __syncthreads() would wait for them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class S, bool FI, class TT, class TRC>
 __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT *&t, TT *&t2, double *Ef, double *Eb,
@@ -984,11 +1067,14 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
             if (myp < n) { bu = gq / (1.0 + (double)pq); bp = myp; }
             wave_argmax_first(bu, bp);
             if (lane == 0) { tc->arg_u[wave] = bu; tc->arg_p[wave] = bp; }
+            if (myp == bp) tc->arg_c[wave] = pq;
         }
         if (tid == 0 && (steps & 63) == 63) {
             const long long el = wall_clock64() - t_start;
             if (el > (long long)(A.watchdog_s * 1e8)) tc->stop = 1;
         }
+        // the one full fence of a step: the counter stored in the previous step (global memory for the compact store) is
+        // complete before any wavefront's scans of this step load it; the utilities' reloads were consumed above anyway
         __syncthreads();
         if (tc->stop) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
         double bu = tc->arg_u[0]; int bp = tc->arg_p[0];
@@ -998,8 +1084,11 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
         }
         STAMP_END(0);
         const int eu = t[bp], ev = t[bp + 1];
-        if (myp == bp && wave < NQ) { (void)s.pen_set(eu, ev, pq); pq += 1; }       // algorithms.py:161
-        __syncthreads();                                     // the incremented counter is visible to every wavefront's scans
+        // algorithms.py:161.  The store is not waited for: every wavefront knows the new count (old + 1, published with the
+        // arg-max) and its scans of this step substitute it for whatever a load of that counter returns
+        const int p_inc = tc->arg_c[bp >> 6] + 1;
+        const int q_inc = PenRowMajor<S>::value ? eu * n + ev : s.idx(eu, ev), q_inc2 = ev * n + eu;   // (row-major: both cells)
+        if (myp == bp && wave < NQ) { (void)s.pen_set(eu, ev, pq); pq += 1; }
         bool moved_this_step = false;
         int s_begin = 0;                                     // first scan (2 endpoint + operator) not consumed yet
         int i1 = bp + 1;                                     // index of endpoint 1 (algorithms.py:169), see header
@@ -1011,42 +1100,66 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
                     if (m) { i1 = p0 + __ffsll((long long)m) - 1; break; }
                 }
             }
+#ifdef GLS_STAMPS
+            const long long tu0 = clock64();
+#endif
             for (int unit = wave; unit < units; unit += nwaves) {
                 const int sc = unit / P, pass = unit - sc * P;
                 const int node = sc >= 2 ? ev : eu;
                 double bd = 0.0; int bk = kNoKey;
                 if (sc >= s_begin && node != 0) {            // algorithms.py:168
                     const int i = sc >= 2 ? i1 : bp;
-                    if ((sc & 1) == 0) scan_two_opt_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n);
-                    else               scan_relocate_o2a_guided<S, FI>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n);
+                    if constexpr (PenRowMajor<S>::value) {
+                        const int j = 1 + pass * kWave + lane;
+                        if ((sc & 1) == 0) scan_two_opt_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, bd, bk);
+                        else               scan_relocate_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, bd, bk);
+                    } else {
+                        if ((sc & 1) == 0) scan_two_opt_o2a_guided<S, FI, TT, true>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n, q_inc, p_inc);
+                        else               scan_relocate_o2a_guided<S, FI, TT, true>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n, q_inc, p_inc);
+                    }
                     if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
                 }
                 if (lane == 0) { tc->res_d[unit] = bd; tc->res_k[unit] = bk; }
             }
             STAMP_END(1);
-            __syncthreads();
-            // consume in the reference's order: endpoint, operator; inside a scan the passes ascend in j
+#ifdef GLS_STAMPS
+            st.acc[12] += clock64() - tu0;       // this wavefront's unit(s) of the round
+            st.acc[13] += 1;
+#endif
+            lds_barrier();
+            // consume in the reference's order: endpoint, operator; inside a scan the passes ascend in j.  Lane u of every
+            // wavefront reads slot u (one LDS round trip for all of them), the first scan with a candidate is one ballot
+            // away and its <= 4 passes are compared through v_readlane
             int found = -1, fk = kNoKey;
-            for (int sc = s_begin; sc < 4 && found < 0; ++sc) {
-                if ((sc >= 2 ? ev : eu) == 0) continue;
-                double bd = 0.0; int bk = kNoKey;
-                for (int pass = 0; pass < P; ++pass) {
-                    const int ok = tc->res_k[sc * P + pass];
-                    if (ok == kNoKey) continue;
-                    const double od = tc->res_d[sc * P + pass];
-                    if (bk == kNoKey || better<FI>(od, ok, bd, bk)) { bd = od; bk = ok; }
+            {
+                const int ku = lane < units ? tc->res_k[lane] : kNoKey;
+                const double du = lane < units ? tc->res_d[lane] : 0.0;
+                const unsigned long long m = __ballot(ku != kNoKey);     // skipped units carry kNoKey
+                const int last = m ? (__ffsll((long long)m) - 1) / P : 3;    // last scan consumed in this round
+                if (tid == 0)
+                    for (int sc = s_begin; sc <= last; ++sc)
+                        if ((sc >= 2 ? ev : eu) != 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
+                if (m) {
+                    found = last;
+                    double bd = 0.0;
+                    const long long dbits = __double_as_longlong(du);
+                    for (int pass = 0; pass < P; ++pass) {
+                        const int li = found * P + pass;
+                        if (!((m >> li) & 1ull)) continue;
+                        const int ok = __builtin_amdgcn_readlane(ku, li);
+                        const int lo = __builtin_amdgcn_readlane((int)dbits, li), hi = __builtin_amdgcn_readlane((int)(dbits >> 32), li);
+                        const double od = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+                        if (fk == kNoKey || better<FI>(od, ok, bd, fk)) { bd = od; fk = ok; }
+                    }
                 }
-                if (tid == 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
-                if (bk != kNoKey) { found = sc; fk = bk; }
             }
             STAMP_END(2);
             if (found < 0) break;
             apply_move(s, t, t2, Ef, Eb, n, found & 1, found >= 2 ? i1 : bp, fk, tid, nthr, eager_cost);   // algorithms.py:175-177
             { TT *x = t; t = t2; t2 = x; }
-            __syncthreads();                                 // also orders this round's slot reads before the next round's writes
+            lds_barrier();                                   // also orders this round's slot reads before the next round's writes
             any_moved = true; moved_this_step = true;
             moves += 1;                                      // algorithms.py:185
-            reload();
             if (eager_cost) {
                 cur_cost = tour_cost_from_edges(Ef, n);      // algorithms.py:176 (every thread: the value stays uniform)
                 if (tid == 0) tr.push(cur_cost);
@@ -1057,6 +1170,10 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
             s_begin = found + 1;
             if (s_begin >= 4) break;
         }
+        // the cached utilities are only read by the next arg-max: ONE reload per step, issued after its last round -- a
+        // reload after every move put its guide-matrix loads (HBM / MALL latency) in front of the next round's penalty
+        // loads of the same wavefront (vector memory returns in order)
+        if (moved_this_step) reload();
         steps++;
         STAMP_COUNT(6);
     }
@@ -1188,6 +1305,8 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             PT *ptri = reinterpret_cast<PT *>(smem + off);
             for (int q = tid; q < ntri; q += nthr) ptri[q] = (PT)0;          // algorithms.py:138
             s.p = ptri; s.limit = A.pen16_limit;
+        } else if constexpr (PenRowMajor<S>::value) {
+            s.p = A.pen_ws + (size_t)b * nn; s.n = n;                         // full matrix, zeroed by the host
         } else {
             s.p = A.pen_ws + (size_t)b * ntri;                                // zeroed by the host
         }
@@ -1425,6 +1544,10 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 #endif
     }
 #ifdef GLS_STAMPS
+    if (TEAM && A.stamps && lane == 0) {      // second region of the stamp buffer: [B,16] per-wavefront unit cycles of the team rounds
+        long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
+        if (wave < 16) o2[wave] = st.acc[12];
+    }
     // per-wavefront view of the descent (waves 1..3; wave 0 is slots 8 / 9) and where the hardware placed each wave:
     // slot 12 = wave 1's arg-min + wait, slots 13..15 = scan cycles of waves 1..3, slot 7 = (SIMD id + 1) << 8 wave
     if (A.stamps && lane == 0) {
@@ -1633,7 +1756,7 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
     if (team && !gls_team_supported(store, penalty_bits, wps, A.n)) return hipErrorInvalidValue;
     size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
     if (store == GLS_STORE_COMPACT) {
-        if (team) return launch_gls_f<TriDGlobalP, 4, true>(A, lds, threads, first_improvement, stream);
+        if (team) return launch_gls_f<TriDGlobalPF, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)
                         : launch_gls_f<TriDGlobalP, 4>(A, lds, threads, first_improvement, stream);
     }

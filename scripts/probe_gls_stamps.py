@@ -17,15 +17,25 @@ if len(sys.argv) > 3 and sys.argv[3] == "noise":
     x = np.triu(x, 1)
     g = torch.from_numpy((x + x.transpose(0, 2, 1))[None]).cuda().contiguous()
     init = ops.nearest_neighbor(g[0]); cost = ops.tour_cost(init, D)
+if len(sys.argv) > 3 and sys.argv[3] == "model":          # the bench's guide: regret_pred of the synthetic (untrained) model
+    from gnngls_amd import pipeline
+    model = pipeline.synthetic_model(seed=1234)
+    R = pipeline.predict_regret(model, D, pipeline.Scalers.fit_weights(D))
+    g = R[None].contiguous()
+    init = ops.nearest_neighbor(R); cost = ops.tour_cost(init, D)
 # the stamp sink is a side buffer registered through the debug hook of the C ABI;
 # trace_cap=0 = the throughput path (trace-free kernel instantiation, deferred tour_cost)
 from gnngls_amd import _lib
-stamps = torch.zeros((B, 16), dtype=torch.int64, device="cuda")
+stamps = torch.zeros((2 * B, 16), dtype=torch.int64, device="cuda")
 _lib.check(_lib.load().gnngls_debug_set_stamp_buffer(_lib.ptr(stamps)))
 tc = int(os.environ.get("TRACE_CAP", "0"))
+_lib.check(_lib.load().gnngls_debug_set_gls_team(int(os.environ.get("TEAM", "-1"))))
+print("config", ops.gls_describe_config(n, B, int(os.environ.get('BITS', '0'))))
 r = ops.gls_run(D, g, init, cost, penalty_bits=int(os.environ.get('BITS', '0')), perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
 torch.cuda.synchronize()
+per_wave = stamps[B:].double().mean(0).cpu().numpy()
+stamps = stamps[:B]
 raw = stamps.cpu().numpy()
 st = stamps.double().mean(0).cpu().numpy()
 assert st.sum() > 0, 'library was not built with GNNGLS_EXTRA_FLAGS=-DGLS_STAMPS'
@@ -46,3 +56,5 @@ simd = [((raw[:, 7] >> (8 * w)) & 0xff) - 1 for w in range(4)]
 import collections
 print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.tolist() for x in simd])).most_common(6))
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
+if per_wave.sum() > 0:
+    print("team rounds: unit cycles per outer iteration, per wavefront:", " ".join(f"{v / it:.0f}" for v in per_wave))

@@ -120,11 +120,15 @@ def test_misc_golden(ops):
     assert_bits(c.cpu().numpy()[0], g["tc_cost"])
 
 
-@pytest.mark.parametrize("team", [0, 1], ids=["serial", "team"])
-@pytest.mark.parametrize("n,B,K", [(7, 16, 6), (20, 32, 10), (33, 16, 6), (64, 8, 4), (65, 8, 4), (100, 16, 3), (130, 4, 2)])
-def test_gls_batch_vs_oracle(ops, n, B, K, team):
+VARIANTS = {"serial": 0, "team": 1}     # form of the perturbation phase
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("n,B,K", [(7, 16, 6), (17, 8, 8), (20, 32, 10), (33, 16, 6), (64, 8, 4), (65, 8, 4), (100, 16, 3), (130, 4, 2)])
+def test_gls_batch_vs_oracle(ops, n, B, K, variant):
     """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup; perturbation phase on wavefront 0
     (serial) and on all wavefronts of the workgroup (team)."""
+    team = VARIANTS[variant]
     from oracle import gls_oracle as go
     rng = np.random.default_rng(1000 + n)
     D, _ = random_instances(rng, B, n)
