@@ -170,6 +170,12 @@ int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *
     return GNNGLS_OK;
 }
 
+int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits) {
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
+        return 0;
+    return gls_config(n, penalty_bits, B).wps;
+}
+
 int gnngls_gls_uses_team(int n, int B, int penalty_bits) {
     if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
         return 0;

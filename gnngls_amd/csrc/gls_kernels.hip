@@ -1705,7 +1705,11 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
         const int waves = threads / kWave;
         const int by_lds = (int)((160 * 1024) / lds);
         const int per_cu4 = by_lds < 16 / waves ? by_lds : 16 / waves;
-        return (batch > 0 && per_cu4 >= 1 && (long)per_cu4 * num_cus >= batch) ? 4 : TriStore<int32_t>::kWavesPerSimd;
+        // ... and only where the smaller register budget actually buys residency (n = 150: one workgroup per CU by LDS
+        // either way -- the 80-VGPR build spills for nothing)
+        const int per_cu6 = by_lds < 24 / waves ? by_lds : 24 / waves;
+        if (batch > 0 && per_cu4 >= 1 && ((long)per_cu4 * num_cus >= batch || per_cu6 <= per_cu4)) return 4;
+        return TriStore<int32_t>::kWavesPerSimd;
     }
     // compact store: the 128-VGPR build unless the batch only fits with 8 waves per SIMD
     const int waves = threads / kWave;

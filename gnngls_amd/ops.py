@@ -200,11 +200,12 @@ class gls_team_mode:
 
 
 def gls_describe_config(n, B=0, penalty_bits=0):
-    """-> dict(store, threads, lds_bytes, per_cu, team): what gnngls_gls_run would use (host-side query)."""
+    """-> dict(store, threads, lds_bytes, per_cu, team, waves_per_simd): what gnngls_gls_run would use (host-side query)."""
     vals = [ctypes.c_int(0) for _ in range(4)]
     _lib.check(_lib.load().gnngls_gls_describe_config(int(n), int(B), int(penalty_bits),
                                                       *[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals]),
                "gls_describe_config")
     names = {0: "global", 116: "lds-tri-u16", 132: "lds-tri-i32", 200: "compact"}
     return {"store": names[vals[0].value], "threads": vals[1].value, "lds_bytes": vals[2].value, "per_cu": vals[3].value,
-            "team": bool(_lib.load().gnngls_gls_uses_team(int(n), int(B), int(penalty_bits)))}
+            "team": bool(_lib.load().gnngls_gls_uses_team(int(n), int(B), int(penalty_bits))),
+            "waves_per_simd": _lib.load().gnngls_gls_waves_per_simd(int(n), int(B), int(penalty_bits))}

@@ -191,6 +191,12 @@ int gnngls_debug_set_penalty16_limit(int limit);
  * instance size).  Used by scripts/probe_gls.py to measure the policy; never called by the product. */
 int gnngls_debug_set_gls_threads(int threads);
 
+/* Register budget of the kernel instantiation gnngls_gls_run would launch for (n, B, penalty_bits), as resident wavefronts
+ * per SIMD: 4 = the 128-VGPR builds (no scratch; every BASELINE.json shape runs on these), 6 / 8 = the 80- / 64-VGPR
+ * builds (56-148 B of scratch per lane) that only batches of small instances beyond 16 workgroups per CU select
+ * (e.g. TSP20 x 5000).  0 = bad argument. */
+int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits);
+
 /* 1 if gnngls_gls_run would run the perturbation phase of this (n, B, penalty_bits) on ALL wavefronts of the workgroup
  * (the "team" form: the four one-to-all scans of a penalty step, algorithms.py:167-174, evaluated concurrently and consumed
  * in the reference's order -- chosen when every workgroup of the batch owns a CU, B <= number of CUs), 0 if on wavefront 0

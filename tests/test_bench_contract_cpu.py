@@ -92,3 +92,35 @@ def test_committed_pmc_figures_follow_from_the_committed_counter_files():
             assert abs(entry[k] - v) <= 1e-9 * max(1.0, abs(v)), k
         else:
             assert entry[k] == v, k
+
+
+def test_shard_and_round_plan_of_an_eight_rank_launch(monkeypatch):
+    """The driver's 8-GPU launch (one process per GPU, WORLD_SIZE=8) cannot be rehearsed on a one-GPU lease: the shard /
+    round arithmetic every rank derives for BASELINE configs[3] (TSP100, 10,000 instances over 8 GPUs) and configs[4]
+    (TSP200 x 256 per GPU) is checked here, and the gather layout it implies."""
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    b = bench_module()
+    from gnngls_amd import parallel
+    # configs[3]: 10,000 instances, strong scaling: 1250 per rank = 2 rounds of 625 at the TSP100 residency of 1024
+    covered = []
+    for rank in range(8):
+        total, lo, hi, sizes = b.shard_plan(10000, 1024, 8, rank)
+        assert total == 10000 and hi - lo == 1250 and sizes == [1250] * 8 and lo == 1250 * rank
+        assert b.round_plan(hi - lo, 0, 1024) == (1024, 2, 625)
+        covered += list(range(lo, hi))
+        D = b.instance_range(2024, 5, lo, min(lo + 3, hi))                    # straddles the seeded 1024-blocks correctly
+        assert D.shape == (3, 5, 5)
+    assert covered == list(range(10000))
+    # an uneven test set: the last rank is short, the sizes every rank computes agree with its own shard
+    for rank in range(8):
+        total, lo, hi, sizes = b.shard_plan(10001, 1024, 8, rank)
+        assert sizes == parallel.shard_sizes(10001, 8) and sizes[rank] == hi - lo and sum(sizes) == 10001
+    # configs[4] per GPU: weak scaling, 256 TSP200 instances per rank, one round at the TSP200 residency (256)
+    for rank in range(8):
+        total, lo, hi, sizes = b.shard_plan(0, 256, 8, rank)
+        assert (total, lo, hi, sizes) == (2048, 1024 * rank, 1024 * rank + 256, None)
+        assert b.round_plan(256, 0, 256) == (256, 1, 256)
+    # headline, weak scaling: block r per rank, all 1024 resident
+    assert b.shard_plan(0, 1024, 8, 7) == (8192, 7168, 8192, None) and b.round_plan(1024, 0, 1024) == (1024, 1, 1024)
+    # a device that cannot keep the instance size resident (capacity query 0) still gets a plan
+    assert b.round_plan(100, 0, 0) == (64, 2, 50) and b.round_plan(0, 0, 1024) == (1024, 0, 1024)

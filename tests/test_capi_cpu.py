@@ -90,7 +90,7 @@ def test_gls_store_selection(lib):
     4-wave workgroups on the 128-VGPR build)."""
     from gnngls_amd import ops
     c = ops.gls_describe_config(100, 1024)
-    assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4, "team": False}
+    assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4, "team": False, "waves_per_simd": 4}
     # perturbation phase on all wavefronts only where every workgroup of the batch owns a CU (B <= 256 CUs) and a
     # one-to-all scan has more than one pass of 64 lanes to share out (n >= 66)
     t200 = ops.gls_describe_config(200, 256)
@@ -103,7 +103,22 @@ def test_gls_store_selection(lib):
     assert ops.gls_describe_config(20, 1000)["threads"] == 64 and ops.gls_describe_config(20, 1000)["per_cu"] >= 4
     assert ops.gls_describe_config(100, 512)["store"] == "lds-tri-i32" and ops.gls_describe_config(100, 512)["per_cu"] == 2
     assert ops.gls_describe_config(100, 513)["store"] == "compact"            # 16-bit LDS counters only on request
-    assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3, "team": False}
+    assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3, "team": False, "waves_per_simd": 6}
     assert ops.gls_describe_config(200, 256)["store"] == "compact" and ops.gls_describe_config(200, 256)["per_cu"] == 1
     assert ops.gls_describe_config(300, 8)["store"] == "global"
     assert 4 * ops.gls_describe_config(100, 1024)["lds_bytes"] == 160 * 1024
+
+
+def test_baseline_shapes_run_on_the_scratch_free_instantiations(lib):
+    """Every BASELINE.json shape (and the rounds a larger test set is cut into) selects a 128-VGPR build of the search kernel
+    (4 resident wavefronts per SIMD; zero scratch: profiles/r03_kernel_resources.txt) and stays fully resident; the 80- /
+    64-VGPR builds (scratch) are only chosen by batches of small instances beyond 16 workgroups per CU."""
+    from gnngls_amd import ops
+    for n, B in ((20, 1000), (50, 128), (50, 2048), (100, 1024), (100, 625), (100, 1250), (200, 256)):
+        c = ops.gls_describe_config(n, B)
+        assert c["waves_per_simd"] == 4, (n, B, c)
+        assert c["per_cu"] * 256 >= min(B, ops.gls_resident_capacity(n)), (n, B, c)
+    spilling = [(n, B) for n in (10, 20, 30, 50, 100, 150, 200) for B in (64, 1024, 1536, 3000, 5000, 8192)
+                if ops.gls_describe_config(n, B)["waves_per_simd"] != 4]
+    assert spilling and all(n <= 50 and B > 1024 for n, B in spilling), spilling
+    assert ops.gls_describe_config(20, 5000)["waves_per_simd"] in (6, 8)

@@ -1,7 +1,7 @@
 """CPU-side hardening (no GPU sanitizers exist on this pool): the C oracle and the host side of the C ABI run under
 AddressSanitizer + UndefinedBehaviorSanitizer.
 
-* oracle/gls_oracle.c, oracle/held_karp.c: rebuilt with gcc -fsanitize=address,undefined and driven through the
+* oracle/gls_oracle.c, oracle/held_karp.c, oracle/one_tree.c: rebuilt with gcc -fsanitize=address,undefined and driven through the
   golden-vector tests in a child interpreter (the sanitizer runtime has to be preloaded into python);
 * gnngls_amd/csrc/capi.hip: compiled HOST-ONLY with the ROCm clang and the same sanitizers, linked with the fuzz driver
   tests/native/capi_fuzz.cpp (hostile arguments: B < 0, n > 65535, NULL pointers, undersized workspaces, bad enums).
@@ -22,13 +22,16 @@ def test_oracle_under_asan_ubsan(tmp_path):
         pytest.skip("gcc has no libasan here")
     so = str(tmp_path / "libgls_oracle_san.so")
     hk = str(tmp_path / "libheld_karp_san.so")
+    one = str(tmp_path / "libone_tree_san.so")
     flags = ["-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra"] + SAN
     subprocess.check_call(["gcc"] + flags + [os.path.join(ROOT, "oracle", "gls_oracle.c"), "-o", so, "-lm"])
     subprocess.check_call(["gcc"] + flags + [os.path.join(ROOT, "oracle", "held_karp.c"), "-o", hk])
+    subprocess.check_call(["gcc"] + flags + [os.path.join(ROOT, "oracle", "one_tree.c"), "-o", one])
     env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", GLS_ORACLE_SO=so,
-               HELD_KARP_SO=hk, UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+               HELD_KARP_SO=hk, ONE_TREE_SO=one, UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-                          os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_held_karp_cpu.py")],
+                          os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_held_karp_cpu.py"),
+                          os.path.join(ROOT, "tests", "test_one_tree_cpu.py")],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "passed" in out.stdout and "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr
