@@ -293,7 +293,7 @@ constexpr int kGatBwdHeads = 2;                    // heads per workgroup (one w
                                                    // 16*kGatBwdHeads columns of ft / dOut, so several workgroups share a CU
                                                    // and the staging of one overlaps the MFMA phase of the others
 constexpr int kGatBwdThreads = 64 * kGatBwdHeads;
-constexpr int kGatBwdMaxTiles = 9;                 // 16-node tiles per row: n - 1 <= 144
+constexpr int kGatBwdMaxTiles = 16;                // 16-node source tiles per row the largest instantiation holds: n - 1 <= 256
 constexpr int LDG = 16 * kGatBwdHeads + 4;         // LDS row stride (floats): a ds_read_b128 of 16 consecutive rows at one
                                                    // column offset touches 16 disjoint groups of 4 banks; 4 rows 4 apart
                                                    // (MFMA B fragment) land on disjoint 16-bank groups  (36, 68, 132)
@@ -314,6 +314,9 @@ __device__ __forceinline__ float row16_sum(float v) {   // inclusive prefix over
 // per tile); inner loop: source tiles st, whose P / del accumulators stay in registers for the whole kernel
 // (kGatBwdMaxTiles x 5 VGPRs), while der of the current destination tile accumulates across st and is reduced over the
 // 16 source lanes once per tile.
+// MAXT = source tiles the instantiation keeps accumulators for (5 VGPRs each): 9 (n <= 145, the reference's training sizes
+// up to TSP100), 13 (n <= 209: TSP200), 16 (n <= 257); the launcher picks the smallest that covers n.
+template <int MAXT>
 __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const float *__restrict__ ft, const float *__restrict__ dout,
                                                                       const float *__restrict__ gout, const float *__restrict__ att,
                                                                       const float *__restrict__ attn_l, const float *__restrict__ attn_r,
@@ -404,10 +407,10 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
     const int jl = lane & 15, q4 = lane >> 4;
     // output row of slot s with the side folded in: slot s is node {u,k}, k = s < u ? s : s+1; side 0 iff u < k iff u <= s
     auto out_row = [&](int s) -> size_t { return ((u <= s) ? 0 : Mtot) + base + nodeS[s]; };
-    f32x4 accP[kGatBwdMaxTiles];
-    float del[kGatBwdMaxTiles];
+    f32x4 accP[MAXT];
+    float del[MAXT];
 #pragma unroll
-    for (int st = 0; st < kGatBwdMaxTiles; ++st) { accP[st] = f32x4{0.f, 0.f, 0.f, 0.f}; del[st] = 0.f; }
+    for (int st = 0; st < MAXT; ++st) { accP[st] = f32x4{0.f, 0.f, 0.f, 0.f}; del[st] = 0.f; }
 
     for (int dt = 0; dt < nt; ++dt) {
         const int ia = dt * 16 + jl, iac = ia < ns ? ia : ns - 1;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
             der[r] = 0.f;
         }
 #pragma unroll
-        for (int st = 0; st < kGatBwdMaxTiles; ++st) {
+        for (int st = 0; st < MAXT; ++st) {
             if (st < nt) {
                 const int j = st * 16 + jl, jc = j < ns ? j : ns - 1;
                 const float el_j = elS[jc * HG + w];
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(kGatBwdThreads) void gat_bwd_rows_kernel(const floa
         }
     }
 #pragma unroll
-    for (int st = 0; st < kGatBwdMaxTiles; ++st) {
+    for (int st = 0; st < MAXT; ++st) {
         if (st < nt) {
             float d = del[st];
             d += __shfl_xor(d, 16, 64);
@@ -712,12 +715,13 @@ size_t gat_bwd_lds_bytes(int n) {
 hipError_t launch_gat_bwd_rows(const float *ft, const float *dout, const float *gout, const float *att, const float *attn_l,
                                const float *attn_r, int B, int n, float *P, float *dlr, hipStream_t st) {
     const size_t lds = gat_bwd_lds_bytes(n);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gat_bwd_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nt = (n - 1 + 15) / 16;
+    auto kern = nt <= 9 ? gat_bwd_rows_kernel<9> : nt <= 13 ? gat_bwd_rows_kernel<13> : gat_bwd_rows_kernel<16>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_bwd_rows_kernel, dim3((unsigned)(B * n * (kH / kGatBwdHeads))), dim3(kGatBwdThreads), lds, st, ft, dout, gout, att, attn_l, attn_r, n,
-                       P, dlr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * n * (kH / kGatBwdHeads))), dim3(kGatBwdThreads), lds, st, ft, dout, gout, att, attn_l,
+                       attn_r, n, P, dlr);
     return hipGetLastError();
 }
 

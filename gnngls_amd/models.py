@@ -78,7 +78,10 @@ class SkipConnection(nn.Module):
 class GATConvParams(nn.Module):
     """Parameters of dgl.nn.GATConv(in_feats, out_feats, num_heads) (models.py:23): fc.weight
     [H*F, in], attn_l / attn_r [1,H,F]; DGL 0.6.1 initialisation (xavier_normal_, gain sqrt(2)).
-    A `bias` [H*F] buffer (DGL >= 0.7 checkpoints) is accepted and folded at pack time."""
+    A `bias` [H*F] parameter (DGL >= 0.7 checkpoints: `rst + bias` after the aggregation) appears when a checkpoint carries
+    one: folded into BatchNorm-1's shift at pack time (inference); in training mode BatchNorm-1 normalises with the batch
+    mean, which absorbs a per-column constant -- the prediction does not depend on it, its gradient is exactly zero, and
+    only the running mean moves by it (see _TrainStep)."""
 
     def __init__(self, in_feats, out_feats, num_heads):
         super().__init__()
@@ -94,7 +97,8 @@ class GATConvParams(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         key = prefix + "bias"
         if key in state_dict and self.bias is None:
-            self.bias = torch.zeros_like(state_dict[key], dtype=torch.float32)   # then loaded like any buffer
+            self._buffers.pop("bias", None)
+            self.register_parameter("bias", nn.Parameter(torch.zeros_like(state_dict[key], dtype=torch.float32)))   # then loaded
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
@@ -176,11 +180,14 @@ class EdgePropertyPredictionModel(nn.Module):
         for layer in self.message_passing_layers:
             gat = layer.message_passing.module
             bn1, ff, bn2 = layer.feed_forward[0], layer.feed_forward[1].module, layer.feed_forward[2]
-            if gat.bias is not None:
-                raise NotImplementedError("training with a GATConv bias (DGL >= 0.7 checkpoints) is not supported")
             out += [gat.fc.weight, gat.attn_l, gat.attn_r, bn1.weight, bn1.bias, ff[0].weight, ff[0].bias,
                     ff[2].weight, ff[2].bias, bn2.weight, bn2.bias]
         return out + [self.decision_layer.weight, self.decision_layer.bias]
+
+    def gat_biases(self):
+        """[(layer index, bias parameter)] of the layers whose GATConv carries a bias (DGL >= 0.7 checkpoints)."""
+        return [(k, layer.message_passing.module.bias) for k, layer in enumerate(self.message_passing_layers)
+                if layer.message_passing.module.bias is not None]
 
     def batch_norms(self):
         return [bn for layer in self.message_passing_layers for bn in (layer.feed_forward[0], layer.feed_forward[2])]
@@ -205,7 +212,8 @@ class EdgePropertyPredictionModel(nn.Module):
         assert in_dim == self.in_dim and total % N == 0 and total == G.number_of_nodes()
         if self.training:                                   # train.py:20-32
             self._check_supported()
-            return _TrainStep.apply(self, x, total // N, n, *self.train_parameters())
+            biases = [b for _, b in self.gat_biases()]
+            return _TrainStep.apply(self, x, total // N, n, len(biases), *self.train_parameters(), *biases)
         return regret_forward(self, x, total // N, n).reshape(total, 1)
 
 
@@ -213,9 +221,10 @@ class _TrainStep(torch.autograd.Function):
     """y_pred = model(batch, x) in training mode as ONE autograd node over the HIP training kernels."""
 
     @staticmethod
-    def forward(ctx, model, x, B, n, *params):
+    def forward(ctx, model, x, B, n, n_bias, *params):
         L = _lib.load()
         dev = x.device
+        params, biases = (params[:-n_bias], params[-n_bias:]) if n_bias else (params, ())
         n_layers = len(model.message_passing_layers)
         image = torch.cat([p.detach().reshape(-1).float() for p in params] + [torch.zeros(3, device=dev)]).contiguous()
         assert image.numel() == L.gnngls_model_packed_floats(model.in_dim, n_layers)
@@ -229,9 +238,14 @@ class _TrainStep(torch.autograd.Function):
         _lib.check(L.gnngls_regret_train_forward(_lib.ptr(x), _lib.ptr(image), B, n, model.in_dim, n_layers, eps,
                                                  _lib.ptr(y), _lib.ptr(stats), _lib.ptr(ws), ctypes.c_int64(ws.numel()),
                                                  _lib.current_stream()), "regret_train_forward")
+        # GATConv bias (DGL >= 0.7): h1 = h + GATConv(h) + bias feeds BatchNorm-1 only; in training mode its batch mean
+        # takes the constant up (variance, prediction and every other gradient unchanged), so the kernels run without it
+        for (k, _), bias in zip(model.gat_biases(), biases):
+            stats[k, 0, 0] += bias.detach().reshape(-1)
         _update_running_stats(bns, stats.reshape(-1, 2, EMBED_DIM))
         ctx.model_dims = (B, n, model.in_dim, n_layers)
         ctx.shapes = [p.shape for p in params]
+        ctx.bias_shapes = [b.shape for b in biases]
         ctx.save_for_backward(x, image)
         ctx.ws = ws
         return y
@@ -255,7 +269,9 @@ class _TrainStep(torch.autograd.Function):
             k = shape.numel()
             out.append(grads[off:off + k].view(shape))
             off += k
-        return (None, None, None, None, *out)
+        # d loss / d bias = column sums of BatchNorm-1's input gradient = 0 exactly (batch statistics)
+        zeros = [torch.zeros(shape, dtype=torch.float32, device=grads.device) for shape in ctx.bias_shapes]
+        return (None, None, None, None, None, *out, *zeros)
 
 
 @torch.no_grad()

@@ -68,23 +68,32 @@ class SolveResult:
     launch_time: torch.Tensor = None   # [B] fp64 host time.time() just before its search kernel was launched
 
 
-def predict_regret(model, D, scalers):
-    """-> 'regret_pred' guide matrices [B,n,n] fp64 (test.py:72-83)."""
+def predict_regret(model, D, scalers, features=None):
+    """-> 'regret_pred' guide matrices [B,n,n] fp64 (test.py:72-83).
+    features: None = the reference's default feature set, the scaled edge weight (datasets.py:14-20 set_features), packed
+    from D on the device; else a [B, N, in_dim] fp32 tensor of ALREADY scaled features in line-graph node order
+    (TSPDataset.get_scaled_features: any feature set, after `feat_drop_idx`), fed to the forward as it is."""
     B, n, _ = D.shape
-    feat = M.pack_features(D, scalers.feat_scale, scalers.feat_min)
+    if features is None:
+        feat = M.pack_features(D, scalers.feat_scale, scalers.feat_min)
+    else:
+        N = n * (n - 1) // 2
+        assert features.dtype == torch.float32 and features.shape[:2] == (B, N) and features.shape[2] == model.in_dim
+        feat = features.to(D.device).reshape(B * N, model.in_dim).contiguous()
     y = M.regret_forward(model, feat, B, n)
     return M.unpack_regret(y, n, scalers.regret_scale, scalers.regret_min)
 
 
 def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit=10.0, perturbation_moves=20,
                 first_improvement=False, max_outer_iters=-1, trace_cap=0, want_trace_time=False, chunk=None,
-                keep_regret=False, budget="per_instance", imp_cap=0):
+                keep_regret=False, budget="per_instance", imp_cap=0, features=None):
     """D [B,n,n] fp64 CUDA tensor (symmetric).  Returns SolveResult with per-instance tensors.
 
     budget="per_instance" (default, the reference's meaning of --time_limit, test.py:64,92): every instance is searched
     for `time_limit` seconds; a batch larger than the device capacity takes ceil(B/capacity) rounds of `time_limit` each.
     budget="per_batch": the whole batch finishes within `time_limit`; the rounds share it equally (each instance is
-    searched for time_limit / rounds) -- the throughput end of the same trade, with the gap there to judge it."""
+    searched for time_limit / rounds) -- the throughput end of the same trade, with the gap there to judge it.
+    features: see predict_regret (None = scaled edge weights packed on the device)."""
     if budget not in ("per_instance", "per_batch"):
         raise ValueError(f"unknown budget policy {budget!r}")
     assert D.is_cuda and D.dtype == torch.float64
@@ -118,7 +127,7 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         t0 = time.time()                                                   # test.py:64
         R = None
         if need_model:
-            R = predict_regret(model, Dc, scalers)
+            R = predict_regret(model, Dc, scalers, None if features is None else features[b0:b0 + chunk])
             torch.cuda.synchronize()
         t1 = time.time()
         # test.py:70-88: the start tour is greedy on 'regret_pred' whenever that guide is used AT ALL (not only when it

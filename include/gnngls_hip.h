@@ -167,7 +167,10 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
  *   forward : feat [B,N,in_dim] -> y_out [B,N]; bn_batch_stats [n_layers][2 (BN1, BN2)][2 (mean, unbiased var)][128]
  *             is what the caller folds into running_mean / running_var (momentum update, torch semantics).
  *   backward: must follow a forward on the SAME workspace (activations are kept there); writes every gradient.
- * n is limited by the register-resident source tiles of the attention backward (n <= 145).  GATConv bias (DGL >= 0.7) is not supported. */
+ * n <= 257 (register-resident source tiles of the attention backward: instantiations for n <= 145, <= 209, <= 257).
+ * A GATConv bias (DGL >= 0.7 checkpoints) is not part of the image: in training mode BatchNorm-1's batch mean absorbs
+ * it (prediction unchanged, gradient exactly zero); the caller adds it to the BatchNorm-1 batch mean it folds into
+ * running_mean (gnngls_amd/models.py:_TrainStep does). */
 int64_t gnngls_regret_train_workspace_bytes(int B, int n, int n_layers);
 int gnngls_regret_train_forward(const float *feat, const float *params, int B, int n, int in_dim, int n_layers, float bn_eps,
                                 float *y_out, float *bn_batch_stats, void *workspace, int64_t workspace_bytes, void *stream);

@@ -119,8 +119,10 @@ class GATConvOracle(nn.Module):
     defaults: feat_drop=attn_drop=0, negative_slope=0.2, residual=False, activation=None, no bias.
     State-dict keys: fc.weight [H*F, in], attn_l [1,H,F], attn_r [1,H,F]."""
 
-    def __init__(self, in_feats, out_feats, num_heads, negative_slope=0.2):
+    def __init__(self, in_feats, out_feats, num_heads, negative_slope=0.2, bias=False):
         super().__init__()
+        # bias=True: DGL >= 0.7 (`rst = rst + bias.view(1, H, F)` after the aggregation); the pinned 0.6.1 has none
+        self.bias = nn.Parameter(torch.zeros(num_heads * out_feats)) if bias else None
         self._num_heads = num_heads
         self._out_feats = out_feats
         self.negative_slope = negative_slope
@@ -140,7 +142,8 @@ class GATConvOracle(nn.Module):
         ft = self.fc(feat).view(-1, H, F)
         el = (ft * self.attn_l).sum(dim=-1)                      # [N,H]
         er = (ft * self.attn_r).sum(dim=-1)                      # [N,H]
-        return gat_aggregate_edge_list(ft, el, er, graph.src, graph.dst, self.negative_slope)
+        rst = gat_aggregate_edge_list(ft, el, er, graph.src, graph.dst, self.negative_slope)
+        return rst if self.bias is None else rst + self.bias.view(1, H, F)
 
 
 def gat_aggregate_edge_list(ft, el, er, src, dst, slope=0.2):
@@ -162,32 +165,49 @@ def gat_aggregate_edge_list(ft, el, er, src, dst, slope=0.2):
 _CHUNK_ELEMS = 1 << 28       # [E,H,F] temporaries above this many elements (2 GiB in fp64) are built per destination range
 
 
+def _gat_chunk(ft, el, er, s_, d_, d0, d1, slope):
+    """gat_aggregate_edge_list restricted to the destinations d0 .. d1-1 (d_ = destination index - d0 of every arc)."""
+    H, F = ft.shape[1], ft.shape[2]
+    e = torch.nn.functional.leaky_relu(el[s_] + er[d0:d1][d_], slope)
+    idx = d_[:, None].expand(-1, H)
+    m = torch.full((d1 - d0, H), -math.inf, dtype=ft.dtype).scatter_reduce(0, idx, e.detach(), reduce="amax", include_self=True)
+    p = torch.exp(e - m[d_])
+    z = torch.zeros((d1 - d0, H), dtype=ft.dtype).index_add_(0, d_, p)
+    w = p / z[d_]
+    return torch.zeros((d1 - d0, H, F), dtype=ft.dtype).index_add_(0, d_, w[:, :, None] * ft[s_])
+
+
 def _gat_aggregate_chunked(ft, el, er, src, dst, slope, arcs_per_chunk=1 << 20):
     """gat_aggregate_edge_list for graphs whose [E,H,F] message tensor does not fit in memory (K_200: 7.9 million arcs x
     128 features): the same formulas on consecutive destination ranges.  Arcs are brought into destination order first
     (stable: every destination's in-arcs keep their original order and sit in one range, so each range is the unchunked
-    computation restricted to those destinations)."""
+    computation restricted to those destinations).  Under autograd every range is a torch.utils.checkpoint segment (its
+    intermediates are recomputed in the backward instead of kept), so a training step of K_200 fits in a few GB.
+    (The row maximum is detached here: the softmax does not depend on the shift; the one-shot form lets autograd carry that
+    term, which cancels to rounding -- tests/test_model_oracle.py compares the gradients of the two forms.)"""
     N, H, F = ft.shape
     if not bool((dst[1:] >= dst[:-1]).all()):
         order = torch.sort(dst, stable=True).indices
         src, dst = src[order], dst[order]
-    out = torch.zeros((N, H, F), dtype=ft.dtype)
+    ckpt = torch.is_grad_enabled() and (ft.requires_grad or el.requires_grad or er.requires_grad)
+    parts = []
     E, a = src.numel(), 0
+    assert int(dst[0]) == 0 and int(dst[-1]) == N - 1
     while a < E:
         b = min(a + arcs_per_chunk, E)
         if b < E:                                                # extend to the end of the last destination's run
             b = int(torch.searchsorted(dst, dst[b - 1], right=True))
         d0, d1 = int(dst[a]), int(dst[b - 1]) + 1
+        assert not parts or d0 == prev_d1                        # every node has in-arcs: the ranges tile 0 .. N-1
         s_, d_ = src[a:b], dst[a:b] - d0
-        e = torch.nn.functional.leaky_relu(el[s_] + er[d0:d1][d_], slope)
-        idx = d_[:, None].expand(-1, H)
-        m = torch.full((d1 - d0, H), -math.inf, dtype=ft.dtype).scatter_reduce(0, idx, e, reduce="amax", include_self=True)
-        p = torch.exp(e - m[d_])
-        z = torch.zeros((d1 - d0, H), dtype=ft.dtype).index_add_(0, d_, p)
-        w = p / z[d_]
-        out[d0:d1] = torch.zeros((d1 - d0, H, F), dtype=ft.dtype).index_add_(0, d_, w[:, :, None] * ft[s_])
+        if ckpt:
+            from torch.utils.checkpoint import checkpoint
+            parts.append(checkpoint(_gat_chunk, ft, el, er, s_, d_, d0, d1, slope, use_reentrant=False))
+        else:
+            parts.append(_gat_chunk(ft, el, er, s_, d_, d0, d1, slope))
+        prev_d1 = d1
         a = b
-    return out
+    return torch.cat(parts)
 
 
 def gat_aggregate_dense(ft, el, er, adj, slope=0.2):
@@ -216,9 +236,9 @@ class _Skip(nn.Module):
 class _AttentionLayer(nn.Module):
     """gnngls/models.py:18-41"""
 
-    def __init__(self, embed_dim, n_heads, hidden_dim):
+    def __init__(self, embed_dim, n_heads, hidden_dim, gat_bias=False):
         super().__init__()
-        self.message_passing = _Skip(GATConvOracle(embed_dim, embed_dim // n_heads, n_heads))
+        self.message_passing = _Skip(GATConvOracle(embed_dim, embed_dim // n_heads, n_heads, bias=gat_bias))
         self.feed_forward = nn.Sequential(
             nn.BatchNorm1d(embed_dim),
             _Skip(nn.Sequential(nn.Linear(embed_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, embed_dim))),
@@ -234,12 +254,12 @@ class EdgeRegretModelOracle(nn.Module):
     """gnngls/models.py:44-70.  NOTE the layer count is `n_heads`, not `n_layers`
     (models.py:59-61 iterates range(n_heads)); hidden width 512 is hard-coded (models.py:60)."""
 
-    def __init__(self, in_dim, embed_dim, out_dim, n_layers, n_heads=1):
+    def __init__(self, in_dim, embed_dim, out_dim, n_layers, n_heads=1, gat_bias=False):
         super().__init__()
         self.embed_dim = embed_dim
         self.embed_layer = nn.Linear(in_dim, embed_dim)
         self.message_passing_layers = nn.Sequential(
-            *(_AttentionLayer(embed_dim, n_heads, 512) for _ in range(n_heads)))
+            *(_AttentionLayer(embed_dim, n_heads, 512, gat_bias) for _ in range(n_heads)))
         self.decision_layer = nn.Linear(embed_dim, out_dim)
 
     def forward(self, G, x):

@@ -80,7 +80,8 @@ def load_model(args, params, test_set):
     print('device =', device)
     if datasets.is_lfs_pointer(args.model_path):
         raise FileNotFoundError(f'{args.model_path} is a git-LFS pointer stub')
-    model = models.EdgePropertyPredictionModel(1, params['embed_dim'], 1, params['n_layers'], n_heads=params['n_heads'])
+    _, feat_dim = test_set[0].ndata['features'].shape                        # test.py:41 (after efeat_drop_idx)
+    model = models.EdgePropertyPredictionModel(feat_dim, params['embed_dim'], 1, params['n_layers'], n_heads=params['n_heads'])
     state = torch.load(args.model_path, map_location=device)['model_state_dict']
     model.load_state_dict(state)
     return model.to(device).eval(), pipeline.Scalers.from_sklearn(test_set.scalers)
@@ -104,14 +105,28 @@ def progress_rows(res, k, full_trace):
     return rows, full_trace > 0
 
 
+def default_feature_set(test_set, G):
+    """True if the instances carry the reference's default edge features -- the edge weight alone (datasets.py:14-20) --
+    and nothing is dropped: the scaled features are then packed from the distance matrix on the device.  Any other
+    feature set goes through TSPDataset.get_scaled_features on the host, exactly as test.py:72 does."""
+    if len(test_set.feat_drop_idx):
+        return False
+    return all(np.shape(G.edges[e]['features']) == (1,) and G.edges[e]['features'][0] == np.float32(G.edges[e]['weight'])
+               for e in G.edges)
+
+
 def solve_block(names, test_set, model, scalers, args, chunk, budget='per_instance'):
     """One batch of instances -> (search-progress records, gaps), the body of the loop at test.py:59-109."""
     graphs = [datasets.read_gpickle(test_set.root_dir / name) for name in names]
     optima = [gnngls_amd.optimal_cost(G, weight='weight') for G in graphs]
     D = torch.from_numpy(np.stack([_attr_matrix(G, 'weight') for G in graphs])).cuda()
+    features = None
+    if model is not None and not default_feature_set(test_set, graphs[0]):
+        features = torch.stack([test_set.get_scaled_features(G).ndata['features'] for G in graphs])      # test.py:72-74
     res = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
                                perturbation_moves=args.perturbation_moves, trace_cap=args.full_trace,
-                               want_trace_time=args.full_trace > 0, chunk=chunk, budget=budget, imp_cap=IMP_CAP)
+                               want_trace_time=args.full_trace > 0, chunk=chunk, budget=budget, imp_cap=IMP_CAP,
+                               features=features)
     res.imp_cost, res.imp_time, res.imp_len = res.imp_cost.cpu(), res.imp_time.cpu(), res.imp_len.cpu()
     res.moves = res.moves.cpu()
     if args.full_trace > 0:

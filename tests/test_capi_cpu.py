@@ -57,7 +57,7 @@ def test_training_entry_points_host_side(lib):
     assert lib.gnngls_regret_train_backward(None, None, None, 1, 100, 1, 8, None, None, 0, None) == -1
     buf = (ctypes.c_float * 16)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.gnngls_regret_train_forward(p, p, 1, 150, 1, 8, 1e-5, p, p, p, 1 << 40, None) == -3      # n > 145
+    assert lib.gnngls_regret_train_forward(p, p, 1, 258, 1, 8, 1e-5, p, p, p, 1 << 40, None) == -3      # n > 257
     assert b"tile limit" in lib.gnngls_last_error()
     assert lib.gnngls_regret_train_forward(p, p, 1, 100, 1, 8, 1e-5, p, p, p, 1024, None) == -1         # workspace too small
     assert b"workspace too small" in lib.gnngls_last_error()

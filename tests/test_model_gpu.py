@@ -136,6 +136,30 @@ def test_forward_headline_batch_instances_alone_and_vs_oracle():
     assert_regret_close(y[511].cpu().numpy(), ref.numpy().reshape(-1))
 
 
+@pytest.mark.parametrize("in_dim,n,B", [(3, 12, 2), (2, 33, 1)])
+def test_forward_multi_feature_input(in_dim, n, B):
+    """Input width other than 1 (test.py:41 takes it from the dataset; the reference's feature sets are built by
+    datasets.py:14-34): embed layer [128, in_dim], same 1e-5 bar against the fp64 oracle."""
+    import copy
+    from gnngls_amd.models import EdgePropertyPredictionModel, LineGraph
+    from oracle import model_oracle as mo
+    torch.manual_seed(20 + in_dim)
+    oracle = mo.EdgeRegretModelOracle(in_dim, 128, 1, 3, n_heads=8)
+    sd = mo.synthetic_state_dict(oracle, seed=7)
+    oracle.load_state_dict(sd)
+    model = EdgePropertyPredictionModel(in_dim, 128, 1, 3, n_heads=8)
+    model.load_state_dict(sd)
+    model.eval().to("cuda")
+    N = n * (n - 1) // 2
+    x = torch.from_numpy(np.random.default_rng(n).random((B * N, in_dim)).astype(np.float32))
+    o64 = copy.deepcopy(oracle).double().eval()
+    with torch.no_grad():
+        y = model(LineGraph(n, batch=B).to("cuda"), x.cuda()).cpu().numpy().reshape(B, N)
+        for b in range(B):
+            ref = o64(mo.line_graph_networkx(n), x[b * N:(b + 1) * N].double()).numpy().reshape(-1)
+            assert_regret_close(y[b], ref)
+
+
 def test_forward_small_workspace_chunks():
     """A workspace that holds one instance at a time gives the same result as the full batch."""
     from gnngls_amd import models as M

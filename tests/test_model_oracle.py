@@ -53,6 +53,21 @@ def test_closed_form_arcs_and_chunked_aggregation(n):
                        mo.gat_aggregate_edge_list(ft, el, er, G.src, G.dst))
 
 
+def test_chunked_aggregation_gradients_match_the_one_shot_form():
+    """Under autograd the destination-range form (checkpointed ranges, what the TSP200 training test differentiates) gives
+    the gradients of the one-shot form."""
+    torch.manual_seed(3)
+    C = mo.line_graph_arcs_closed_form(8)
+    N = C.number_of_nodes()
+    leaves = [torch.randn(N, 8, 16, dtype=torch.float64, requires_grad=True),
+              torch.randn(N, 8, dtype=torch.float64, requires_grad=True), torch.randn(N, 8, dtype=torch.float64, requires_grad=True)]
+    wgt = torch.randn(N, 8, 16, dtype=torch.float64)
+    ga = torch.autograd.grad((mo.gat_aggregate_edge_list(*leaves, C.src, C.dst) * wgt).sum(), leaves)
+    gb = torch.autograd.grad((mo._gat_aggregate_chunked(*leaves, C.src, C.dst, 0.2, arcs_per_chunk=50) * wgt).sum(), leaves)
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, rtol=1e-11, atol=1e-12)
+
+
 def build_oracle_model():
     g = np.load(os.path.join(GOLD, "model_n5.npz"))
     torch.manual_seed(int(g["model_seed"]))

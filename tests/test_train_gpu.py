@@ -144,6 +144,88 @@ def test_train_step_vs_oracle(n, B):
             assert torch.equal(bufs[k], ref64), k
 
 
+def one_layer(m):
+    """Keep the first AttentionLayer only (the C ABI takes the layer count; the oracle iterates what is there): the fp64
+    autograd oracle of a TSP150 / TSP200 step stays within a few GB and a minute."""
+    m.message_passing_layers = m.message_passing_layers[:1]
+    return m
+
+
+@pytest.mark.parametrize("n", [150, 200])
+def test_train_step_vs_oracle_beyond_the_old_tile_limit(n):
+    """n > 145 (TSP200 = BASELINE configs[4]): the attention backward's instantiations with 13 source tiles per row;
+    forward through the head-split gat_rows_kernel.  One layer, one instance, every gradient tensor against the fp64
+    oracle (arcs from the closed-form rule, checkpointed destination ranges: tests/test_model_oracle.py)."""
+    from oracle import model_oracle as mo
+    model, oracle = make_models(4321, 77)
+    model, oracle = one_layer(model), one_layer(oracle)
+    oracle64 = copy.deepcopy(oracle).double()
+    N = n * (n - 1) // 2
+    rng = np.random.default_rng(n)
+    x = torch.from_numpy(rng.random((N, 1)).astype(np.float32))
+    target = torch.from_numpy(rng.random((N, 1)).astype(np.float32))
+    G = mo.line_graph_arcs_closed_form(n)
+    y32, loss32, g32, b32 = mo.train_step_reference(oracle, G, x, target)
+    y64, loss64, g64, b64 = mo.train_step_reference(oracle64, G, x.double(), target.double())
+    y, loss, grads, bufs = hip_step(model, n, 1, x, target)
+    own = np.abs(y32.double().numpy() - y64.numpy()).max()
+    err, ref = np.abs(y.double().numpy() - y64.numpy()).reshape(-1), np.abs(y64.numpy()).reshape(-1)
+    assert (err <= 1e-5 * ref + 1e-5 * ref.max() + 3 * own).all(), f"pred err {err.max():.3e} (fp32 oracle {own:.3e})"
+    assert abs(loss - loss64.item()) <= 1e-5 * loss64.item() + 3 * abs(loss32.item() - loss64.item())
+    m = gradient_error_metrics(grads, g32, g64)
+    assert gradient_errors_acceptable(m), m
+    for k, ref64 in b64.items():
+        if ref64.dtype.is_floating_point:
+            assert torch.allclose(bufs[k].double(), ref64, rtol=2e-5, atol=1e-6), k
+
+
+def test_train_step_with_gatconv_bias():
+    """A checkpoint with GATConv `bias` keys (DGL >= 0.7): training works, predictions and all other gradients equal the
+    oracle's (whose GATConv adds the bias after the aggregation), the bias gradient is zero (BatchNorm-1 normalises with the
+    batch mean) and the BatchNorm-1 running mean moves by the bias."""
+    from gnngls_amd.models import EdgePropertyPredictionModel
+    from oracle import model_oracle as mo
+    torch.manual_seed(99)
+    oracle = mo.EdgeRegretModelOracle(1, 128, 1, 3, n_heads=8, gat_bias=True)
+    sd = mo.synthetic_state_dict(oracle, seed=5)
+    gen = torch.Generator().manual_seed(6)
+    for k in list(sd):
+        if k.endswith("message_passing.module.bias"):
+            sd[k] = 0.3 * torch.randn(sd[k].shape, generator=gen)
+    oracle.load_state_dict(sd)
+    model = EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+    res = model.load_state_dict(sd)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.to("cuda")
+    assert len(model.gat_biases()) == 8 and all(b.is_cuda and b.requires_grad for _, b in model.gat_biases())
+    n, B = 12, 3
+    N = n * (n - 1) // 2
+    rng = np.random.default_rng(12)
+    x = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32))
+    target = torch.from_numpy(rng.random((B * N, 1)).astype(np.float32))
+    G = mo.batch_line_graphs(n, B)
+    oracle64 = copy.deepcopy(oracle).double()
+    y32, loss32, g32, b32 = mo.train_step_reference(oracle, G, x, target)
+    y64, loss64, g64, b64 = mo.train_step_reference(oracle64, G, x.double(), target.double())
+    y, loss, grads, bufs = hip_step(model, n, B, x, target)
+    assert_pred_close(y.numpy(), y64.numpy(), rtol=3e-5)
+    bias_keys = [k for k in g64 if k.endswith("message_passing.module.bias")]
+    assert len(bias_keys) == 8
+    gmax = max(v.abs().max().item() for v in g64.values())
+    for k in bias_keys:
+        assert grads[k].abs().max().item() == 0.0 and g64[k].abs().max().item() <= 1e-9 * gmax        # exactly zero / rounding
+    assert gradient_errors_acceptable(gradient_error_metrics(grads, g32, g64))
+    for k, ref64 in b64.items():
+        if ref64.dtype.is_floating_point:
+            assert torch.allclose(bufs[k].double(), ref64, rtol=2e-5, atol=1e-6), k          # incl. running_mean shifted by the bias
+    # and the same checkpoint in inference mode (bias folded into BatchNorm-1's shift)
+    from gnngls_amd.models import LineGraph
+    with torch.no_grad():
+        ye = model.eval()(LineGraph(n, batch=B).to("cuda"), x.cuda()).cpu().numpy()
+        re = oracle64.eval()(G, x.double()).numpy()
+    assert_pred_close(ye, re)
+
+
 def test_gradient_error_statistics():
     """Over a set of seeded random cases the HIP gradient errors are not larger than the fp32 CPU oracle's (medians)."""
     from oracle import model_oracle as mo
@@ -239,7 +321,7 @@ def test_training_rejects_unsupported_sizes():
     from gnngls_amd.models import LineGraph
     model, _ = make_models(4321, 77)
     model.train()
-    n = 150                                     # beyond the attention-backward tile limit (n <= 145)
+    n = 258                                     # beyond the attention-backward tile limit (n <= 257)
     x = torch.zeros((n * (n - 1) // 2, 1), device="cuda")
     with pytest.raises(_lib.GnnglsHipError):
         model(LineGraph(n).to("cuda"), x)
