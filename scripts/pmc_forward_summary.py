@@ -39,14 +39,15 @@ def main():
         simd_cycles = 1024 * t_m[k] * clock
         clock_v = va[k]["GRBM_GUI_ACTIVE"] / 8 / t_v[k]
         out[k] = {
-            "mfma_busy_frac": mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"] * 4 / simd_cycles,
+            # (this counter is in shader cycles, not in the 4-cycle ticks of the SQ_ACTIVE_* / SQ_BUSY_* counters: with x4 the
+            # fused FFN would be 3.06 of its own SIMD cycles; as it is, 0.765 -- its algorithmic 0.755 of the fp32 MFMA peak)
+            "mfma_busy_frac": mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles,
             "wave_wait_frac": mf[k]["SQ_WAIT_ANY"] / mf[k]["SQ_WAVE_CYCLES"],
             "valu_busy_frac": va[k]["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * t_v[k] * clock_v),
             "lds_busy_frac": va[k]["SQ_LDS_IDX_ACTIVE"] / (256 * t_v[k] * clock_v),
             "lds_bank_conflict_frac": va[k]["SQ_LDS_BANK_CONFLICT"] / max(va[k]["SQ_LDS_IDX_ACTIVE"], 1.0),
             "valu_insts_per_mfma": va[k]["SQ_INSTS_VALU"] / max(va[k]["SQ_INSTS_MFMA"], 1.0),
             "hbm_bytes_per_row": (fe[k]["FETCH_SIZE"] / n_f[k] + wr[k]["WRITE_SIZE"] / n_w[k]) * 1024 / rows_per_launch,
-            "avg_launch_ms": t_m[k] / (sum(1 for _ in [0]) and max(n_f[k], 1)) * 1e3 * n_f[k] / max(n_f[k], 1),
             "clock_ghz": clock / 1e9,
         }
         out[k]["avg_launch_ms"] = t_f[k] / max(n_f[k], 1) * 1e3
