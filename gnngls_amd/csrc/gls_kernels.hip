@@ -44,6 +44,10 @@ namespace gnngls {
 #ifndef GLS_PERTURB_PRIO
 #define GLS_PERTURB_PRIO 3           // s_setprio of the wavefront that carries the perturbation phase
 #endif
+#ifndef GLS_NODE_LANES
+#define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
+                                     // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
+#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
 #endif
@@ -707,19 +711,26 @@ __device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, 
     }
 }
 
+// pos != nullptr: lane l of row block rb owns NODE b = 1 + 64 rb + l (wherever it sits in the tour: i = pos[b]) instead of
+// tour POSITION 1 + 64 rb + l.  The random read of a step is D[b, e] with e wave-uniform: with consecutive node ids on the
+// lanes the half of the lanes with b < e reads 64 consecutive doubles of row e and the other half a fixed quadratic
+// pattern (b(b-1)/2 + e), instead of 64 arbitrary rows / columns: simulated 2.5 instead of 4.9 bank passes per
+// ds_read_b64 at n = 100.  Keys (i, j) and deltas are the same set; within a lane they still ascend with k.
 template <int SL, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, const double *Ef, int n,
-                                                       int wave, int nwaves, int lane, double &bd, int &bk) {
+                                                       int wave, int nwaves, int lane, double &bd, int &bk,
+                                                       const uint8_t *pos = nullptr) {
     const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows
     const int per_rb = nwaves / RW;                          // waves sharing a row block, each a contiguous k range
     const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
     const int part = __builtin_amdgcn_readfirstlane(wave - rb * per_rb);
     if (per_rb == 0 || rb >= RW) return;                     // callers guarantee nwaves >= RW; surplus waves idle
     const LaneTour<SL> L = load_lane_tour<SL>(t, n, lane);
-    const int i = 1 + rb * kWave + lane;
-    const bool row_ok = i <= n - 1;                          // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
+    const int own = 1 + rb * kWave + lane;                   // the lane's row: a position, or a node id (pos != nullptr)
+    const bool row_ok = own <= n - 1;                        // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
+    const int i = pos ? (int)pos[row_ok ? own : 1] : own;
     const int ic = row_ok ? i : 1;
-    const int a = t[ic - 1], b = t[ic], cc = t[ic + 1];
+    const int a = t[ic - 1], b = pos ? (row_ok ? own : (int)t[1]) : (int)t[ic], cc = t[ic + 1];
     double base = -Ef[ic];                                   // -D[a,b]
     base = base - Ef[ic + 1];                                // -D[b,c]
     base = base + s.dist(a, cc);                             // +D[a,c]
@@ -922,12 +933,15 @@ __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, c
 }
 
 // new tour + edge arrays in one pass; caller synchronises afterwards.
+// pos (descent with node-indexed relocate lanes): node -> position table, kept current here
 template <class S, class TT>
 __device__ __forceinline__ void apply_move(const S &s, const TT *told, TT *tnew, double *Ef, double *Eb,
-                                           int n, int op, int i, int j, int tid, int nthr, bool want_edges) {
+                                           int n, int op, int i, int j, int tid, int nthr, bool want_edges,
+                                           uint8_t *pos = nullptr) {
     for (int p = tid; p <= n; p += nthr) {
         int np = told[move_src(op, p, i, j)];
         tnew[p] = (TT)np;
+        if (pos && p < n) pos[np] = (uint8_t)p;
         if (want_edges && p >= 1) {
             int nq = told[move_src(op, p - 1, i, j)];
             Ef[p] = s.dist(nq, np);
@@ -1212,7 +1226,15 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
+    // node -> position table of the node-indexed relocate scan: n <= 104 bytes in the exchange slots of Ctl that the
+    // best-improvement descent never touches (its LDS-atomic arg-min uses the first 24 bytes of red_d and 12 of red_k;
+    // the compact store's 40 KiB at n = 100 have no other byte to spare)
+    constexpr int kPosBytes = (int)sizeof(ctl->red_d) - 3 * (int)sizeof(double);
+    uint8_t *pos = (!FI && S::kSymmetric && GLS_NODE_LANES && n <= kPosBytes && n <= GP * kWave - 1 &&
+                    nwaves >= (n - 1 + kWave - 1) / kWave)
+                       ? reinterpret_cast<uint8_t *>(&ctl->red_d[0][3]) : nullptr;
     build_edges(s, t, Ef, Eb, n, tid, nthr);
+    if (pos) for (int p = tid; p < n; p += nthr) pos[t[p]] = (uint8_t)p;
     __syncthreads();
     bool improved = true;
     while (improved) {                                               // algorithms.py:116
@@ -1229,7 +1251,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
                 // (GP = register slots of the perturbation phase = the same 2 / 4, chosen by the launcher from n)
                 if (nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
                     if (op == 0) scan_two_opt_a2a_lean<GP, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
-                    else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
+                    else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
                     lean = true;
                 }
             }
@@ -1250,7 +1272,7 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
-                apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true);
+                apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos);
                 TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();

@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -o 
 find gpurun_out/$tag/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/$tag/${tag}_kernel_stats.csv \;
 python bench.py --n 50 --batch 128 --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/$tag/${tag}_bench_tsp50x128.json 2>> gpurun_out/$tag/bench.err
 python bench.py --n 200 --batch 256 --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/$tag/${tag}_bench_tsp200x256.json 2>> gpurun_out/$tag/bench.err
-python bench.py --n 50 --batch 2048 --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/$tag/${tag}_bench_tsp50x2048.json 2>> gpurun_out/$tag/bench.err
+python bench.py --n 50 --total_instances 2048 --steps 1 --warmup 1 --no_cpu_baseline > gpurun_out/$tag/${tag}_bench_tsp50x2048.json 2>> gpurun_out/$tag/bench.err
 python bench.py --n 20 --batch 1000 --steps 1 --warmup 1 --no_cpu_baseline --exact_gap > gpurun_out/$tag/${tag}_bench_tsp20x1000_exact_gap.json 2>> gpurun_out/$tag/bench.err
 rm -rf gpurun_out/$tag/prof
 ls -la gpurun_out/$tag
