@@ -319,6 +319,16 @@ __device__ __forceinline__ void wave_min_value_key(double &d, int &k) {
     const unsigned long long sk = sortable(d);
     const unsigned hi = (unsigned)(sk >> 32), lo = (unsigned)sk;
     const unsigned mhi = wave_umin(hi);
+    // the high words of two candidates' deltas almost never tie: one lane left -> its low word and key by v_readlane,
+    // the other two reductions (2 x 6 dependent DPP steps) only run on a tie
+    const unsigned long long tie = __ballot(hi == mhi);
+    if ((tie & (tie - 1)) == 0ull) {
+        const int src = __ffsll((long long)tie) - 1;
+        const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+        d = unsortable(((unsigned long long)mhi << 32) | mlo);
+        k = __builtin_amdgcn_readlane(k, src);
+        return;
+    }
     const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
     const unsigned mk = wave_umin((hi == mhi && lo == mlo) ? (unsigned)k : 0x7fffffffu);
     d = unsortable(((unsigned long long)mhi << 32) | mlo);
@@ -349,6 +359,14 @@ __device__ __forceinline__ void wave_argmax_first(double &v, int &pos) {
     if (pos == kNoKey) sk = ~0ull;
     const unsigned hi = (unsigned)(sk >> 32), lo = (unsigned)sk;
     const unsigned mhi = wave_umin(hi);
+    const unsigned long long tie = __ballot(hi == mhi);      // as in wave_min_value_key: usually one lane is left
+    if ((tie & (tie - 1)) == 0ull) {
+        const int src = __ffsll((long long)tie) - 1;
+        const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+        v = unsortable(~(((unsigned long long)mhi << 32) | mlo));
+        pos = __builtin_amdgcn_readlane(pos, src);
+        return;
+    }
     const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
     const unsigned mp = wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
     v = unsortable(~(((unsigned long long)mhi << 32) | mlo));
