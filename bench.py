@@ -139,6 +139,9 @@ def kernel_rooflines(prof, n, B_chunk, n_layers):
     for name, v in out.items():
         if name in traffic and "hbm_bytes_per_row" in traffic[name]:
             v["traffic"] = traffic[name]["hbm_bytes_per_row"] * M
+        if name in traffic and "mfma_busy_frac" in traffic[name]:       # committed SQ_VALU_MFMA_BUSY_CYCLES pass (profiles/r03_pmc_forward)
+            v["pmc"] = {k: traffic[name][k] for k in ("mfma_busy_frac", "valu_busy_frac", "lds_busy_frac", "valu_insts_per_mfma",
+                                                      "wave_wait_frac", "source") if k in traffic[name]}
     if "gat_aggregate" in out:
         t = out["gat_aggregate"]["avg_launch_ms"] * 1e-3
         out["gat_aggregate"]["algorithmic_gbs"] = k1_bytes / t / 1e9

@@ -63,8 +63,10 @@ def main():
     }
     print(json.dumps(e, indent=1))
     if "--write" in sys.argv:
-        p = os.path.join(ROOT, "profiles", "traffic_r02.json")
-        t = json.load(open(p))
+        # profiles/traffic_<round>.json, the round taken from the directory name (r03_pmc -> traffic_r03.json)
+        rnd = os.path.basename(os.path.normpath(d)).split("_")[0][:3]
+        p = os.path.join(ROOT, "profiles", f"traffic_{rnd}.json")
+        t = json.load(open(p)) if os.path.isfile(p) else {}
         t["gls_kernel"] = e
         json.dump(t, open(p, "w"), indent=1)
         print("updated", p)

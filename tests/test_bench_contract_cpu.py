@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -73,15 +74,16 @@ def test_instance_blocks_and_best_known_file(tmp_path):
     assert b.load_best_known(str(tmp_path / "none.npz"), 6, 7, 0, 10)[0] is None
 
 
-def test_committed_pmc_figures_follow_from_the_committed_counter_files():
-    """profiles/traffic_r02.json's gls_kernel entry (what bench.py prints as roofline.pmc / roofline.traffic) is exactly what
-    scripts/pmc_summary.py derives from the counter CSVs it names -- no hand-edited numbers."""
-    import json
-    import os
+@pytest.mark.parametrize("traffic", ["traffic_r02.json", "traffic_r03.json"])
+def test_committed_pmc_figures_follow_from_the_committed_counter_files(traffic):
+    """The gls_kernel entry of profiles/traffic_r0*.json (what bench.py prints as roofline.pmc / roofline.traffic) is exactly
+    what scripts/pmc_summary.py derives from the counter CSVs it names -- no hand-edited numbers; likewise the forward
+    kernels' entries of round 3 and scripts/pmc_forward_summary.py."""
     import subprocess
     import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    entry = json.load(open(os.path.join(root, "profiles", "traffic_r02.json")))["gls_kernel"]
+    root = ROOT
+    table = json.load(open(os.path.join(root, "profiles", traffic)))
+    entry = table["gls_kernel"]
     src = entry["source"].split("/*_counter_collection.csv")[0]
     assert os.path.isdir(os.path.join(root, src)), src
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_summary.py"), os.path.join(root, src)],
@@ -92,6 +94,15 @@ def test_committed_pmc_figures_follow_from_the_committed_counter_files():
             assert abs(entry[k] - v) <= 1e-9 * max(1.0, abs(v)), k
         else:
             assert entry[k] == v, k
+    if "mfma_busy_frac" in table.get("ffn_fused", {}):
+        fsrc = table["ffn_fused"]["source"].split("/*_counter_collection.csv")[0]
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_forward_summary.py"), os.path.join(root, fsrc)],
+                             capture_output=True, text=True, check=True).stdout
+        derived = json.loads(out)
+        for name, kern in (("ffn_fused", "ffn_fused_kernel"), ("gemm_fc", "gemm_f32_kernel"), ("gat_aggregate", "gat_rows_kernel")):
+            for k, v in derived[kern].items():
+                assert abs(table[name][k] - v) <= 1e-9 * max(1.0, abs(v)), (name, k)
+            assert 0.3 < table[name]["mfma_busy_frac"] < 1.0
 
 
 def test_shard_and_round_plan_of_an_eight_rank_launch(monkeypatch):
