@@ -79,16 +79,19 @@ struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per
 GlsConfig gls_config_store(int n, int requested_bits, int batch);
 
 // + the form of the perturbation phase: on all wavefronts of the workgroup (team) when every workgroup of the batch gets a
-// CU of its own -- B <= number of CUs: TSP200 x 256 (one 16-wave workgroup per CU by LDS anyway), TSP50 x 128 -- else on
-// wavefront 0 (the CU is shared, the other workgroups' descents fill the SIMDs)
+// CU of its own (B <= number of CUs) and is a 16-wave workgroup (TSP200 x 256: one per CU by LDS anyway) -- else on
+// wavefront 0
 GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
     GlsConfig c = gls_config_store(n, requested_bits, batch);
     const int mode = g_team_mode.load(std::memory_order_relaxed);
     if (mode != 0 && gnngls::gls_team_supported(c.store, c.penalty_bits, c.wps, n)) {
         const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, true);
-        // ... and a one-to-all scan has at least two passes of 64 lanes to share out (n >= 66): with one pass per scan a
-        // round of the team form costs what the four serial scans cost (TSP50 x 128: 18.3k vs 21.2k iterations in 2 s)
-        const bool pays = batch > 0 && batch <= num_cus() && n - 1 > 64;
+        // ... and only for the 16-wave workgroups that own a CU by their LDS footprint (distance triangle > 80 KB: n >= 144,
+        // TSP200).  Measured (outer iterations in 2 s, team vs serial): TSP200 x 256 13.0k vs 10.9k (weight guide), 10.5k vs
+        // 10.3k (regret_pred of the synthetic model), 6.7k vs 6.8k (noise); but TSP100 x 256 on 8-wave workgroups 20.3k vs
+        // 24.2k (model guide) and TSP50 x 128 (one pass per scan) 18.3k vs 21.2k: a round's barriers, slot exchange and
+        // the re-evaluation after a move cost more than the few passes they save (profiles/r03_experiments/README.md)
+        const bool pays = batch > 0 && batch <= num_cus() && c.store == gnngls::GLS_STORE_COMPACT && c.threads == 1024;
         if (lds <= kLdsPerCU && (mode == 1 || pays)) { c.team = true; c.lds = lds; }
     }
     return c;

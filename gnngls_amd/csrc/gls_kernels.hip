@@ -44,6 +44,9 @@ namespace gnngls {
 #ifndef GLS_PERTURB_PRIO
 #define GLS_PERTURB_PRIO 3           // s_setprio of the wavefront that carries the perturbation phase
 #endif
+#ifndef GLS_TEAM_SCANS
+#define GLS_TEAM_SCANS 4             // team form: one-to-all scans evaluated per round (4 = both endpoints, 2 = one endpoint, 1)
+#endif
 #ifndef GLS_NODE_LANES
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
@@ -1062,7 +1065,7 @@ __device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k
 struct TeamCtl {
     double arg_u[4]; int arg_p[4];       // partial arg-max of the utilities, per block of 64 tour positions
     int arg_c[4];                        // penalty counter of that block's arg-max edge
-    double res_d[16]; int res_k[16];     // candidate of unit (scan, pass): scan = 2 endpoint + operator
+    double res_d[2][16]; int res_k[2][16];   // candidate of unit (scan, pass): scan = 2 endpoint + operator; two sets, by round parity
     int stop; int pad[3];
 };
 
@@ -1124,7 +1127,9 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
         bool moved_this_step = false;
         int s_begin = 0;                                     // first scan (2 endpoint + operator) not consumed yet
         int i1 = bp + 1;                                     // index of endpoint 1 (algorithms.py:169), see header
-        for (;;) {
+        for (int round = 0;; ++round) {
+            const int s_end = (s_begin / GLS_TEAM_SCANS + 1) * GLS_TEAM_SCANS;      // scans evaluated in this round: [s_begin, s_end)
+            double *res_d = tc->res_d[round & 1]; int *res_k = tc->res_k[round & 1];
             if (moved_this_step && s_begin <= 2) {           // endpoint 1 not started: cur_tour.index(ev) on the current tour
                 for (int p0 = 0; p0 <= n; p0 += kWave) {
                     const int p = p0 + lane;
@@ -1139,7 +1144,7 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
                 const int sc = unit / P, pass = unit - sc * P;
                 const int node = sc >= 2 ? ev : eu;
                 double bd = 0.0; int bk = kNoKey;
-                if (sc >= s_begin && node != 0) {            // algorithms.py:168
+                if (sc >= s_begin && sc < s_end && node != 0) {      // algorithms.py:168
                     const int i = sc >= 2 ? i1 : bp;
                     if constexpr (PenRowMajor<S>::value) {
                         const int j = 1 + pass * kWave + lane;
@@ -1151,7 +1156,7 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
                     }
                     if (__ballot(bk != kNoKey)) wave_reduce_best<FI>(bd, bk);
                 }
-                if (lane == 0) { tc->res_d[unit] = bd; tc->res_k[unit] = bk; }
+                if (lane == 0) { res_d[unit] = bd; res_k[unit] = bk; }
             }
             STAMP_END(1);
 #ifdef GLS_STAMPS
@@ -1164,10 +1169,10 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
             // away and its <= 4 passes are compared through v_readlane
             int found = -1, fk = kNoKey;
             {
-                const int ku = lane < units ? tc->res_k[lane] : kNoKey;
-                const double du = lane < units ? tc->res_d[lane] : 0.0;
+                const int ku = lane < units ? res_k[lane] : kNoKey;
+                const double du = lane < units ? res_d[lane] : 0.0;
                 const unsigned long long m = __ballot(ku != kNoKey);     // skipped units carry kNoKey
-                const int last = m ? (__ffsll((long long)m) - 1) / P : 3;    // last scan consumed in this round
+                const int last = m ? (__ffsll((long long)m) - 1) / P : s_end - 1;   // last scan consumed in this round
                 if (tid == 0)
                     for (int sc = s_begin; sc <= last; ++sc)
                         if ((sc >= 2 ? ev : eu) != 0) evals += (sc & 1) == 0 ? (n - 3) : (n - 2);
@@ -1186,10 +1191,14 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
                 }
             }
             STAMP_END(2);
-            if (found < 0) break;
+            if (found < 0) {
+                if (s_end >= 4) break;
+                s_begin = s_end;                             // nothing in this group of scans: on to the next one
+                continue;
+            }
             apply_move(s, t, t2, Ef, Eb, n, found & 1, found >= 2 ? i1 : bp, fk, tid, nthr, eager_cost);   // algorithms.py:175-177
             { TT *x = t; t = t2; t2 = x; }
-            lds_barrier();                                   // also orders this round's slot reads before the next round's writes
+            lds_barrier();
             any_moved = true; moved_this_step = true;
             moves += 1;                                      // algorithms.py:185
             if (eager_cost) {

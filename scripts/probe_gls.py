@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 Bs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 512, 1024]
 tl = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
 bits = int(sys.argv[4]) if len(sys.argv) > 4 else 0              # penalty_bits: 0 auto, -2 compact store, 32 / 16 LDS counters
-guide_kind = sys.argv[5] if len(sys.argv) > 5 else "weight"      # weight | noise (clamped fp32 noise, like an untrained model)
+guide_kind = sys.argv[5] if len(sys.argv) > 5 else "weight"      # weight | noise (clamped fp32 noise) | model (regret_pred of the synthetic model, what bench.py uses)
 threads = int(sys.argv[6]) if len(sys.argv) > 6 else 0           # workgroup size override (0 = default policy)
 team = int(sys.argv[7]) if len(sys.argv) > 7 else -1             # perturbation phase: -1 policy, 0 wavefront 0, 1 all wavefronts
 from gnngls_amd import _lib  # noqa: E402
@@ -32,6 +32,12 @@ for B in Bs:
         x = np.triu(x, 1)
         g = torch.from_numpy((x + x.transpose(0, 2, 1))[None]).cuda().contiguous()
         init = ops.nearest_neighbor(g[0])
+        cost = ops.tour_cost(init, D)
+    if guide_kind == "model":                                 # bench.py's guide: regret_pred of the synthetic model
+        from gnngls_amd import pipeline
+        R = pipeline.predict_regret(pipeline.synthetic_model(seed=1234), D, pipeline.Scalers.fit_weights(D))
+        g = R[None].contiguous()
+        init = ops.nearest_neighbor(R)
         cost = ops.tour_cost(init, D)
     torch.cuda.synchronize()
     t0 = time.time()

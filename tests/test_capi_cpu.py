@@ -91,12 +91,13 @@ def test_gls_store_selection(lib):
     from gnngls_amd import ops
     c = ops.gls_describe_config(100, 1024)
     assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4, "team": False, "waves_per_simd": 4}
-    # perturbation phase on all wavefronts only where every workgroup of the batch owns a CU (B <= 256 CUs) and a
-    # one-to-all scan has more than one pass of 64 lanes to share out (n >= 66)
+    # perturbation phase on all wavefronts only where every workgroup of the batch owns a CU (B <= 256 CUs) and is a
+    # 16-wave workgroup (one per CU by its LDS footprint: n >= 144)
     t200 = ops.gls_describe_config(200, 256)
     assert t200["store"] == "compact" and t200["team"] and t200["threads"] == 1024 and t200["lds_bytes"] <= 160 * 1024
     assert not ops.gls_describe_config(200, 257)["team"] and not ops.gls_describe_config(50, 128)["team"]
-    assert ops.gls_describe_config(100, 256)["team"] and ops.gls_describe_config(66, 8)["team"] and not ops.gls_describe_config(65, 8)["team"]
+    assert not ops.gls_describe_config(100, 256)["team"] and not ops.gls_describe_config(130, 8)["team"]
+    assert ops.gls_describe_config(150, 8, penalty_bits=-2)["team"] and not ops.gls_describe_config(160, 200)["team"]   # 8-wave LDS-penalty store
     assert not ops.gls_describe_config(100, 128, penalty_bits=16)["team"] and not ops.gls_describe_config(300, 8)["team"]
     assert ops.gls_resident_capacity(100) == 1024 and ops.gls_resident_capacity(50) == 2048
     assert ops.gls_describe_config(50, 1024)["per_cu"] >= 4 and ops.gls_describe_config(50, 2048)["per_cu"] == 8

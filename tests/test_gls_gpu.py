@@ -170,7 +170,8 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
     from oracle import gls_oracle as go
     cfg = ops.gls_describe_config(n, B, penalty_bits=bits)
     assert cfg["store"] == store and cfg["per_cu"] == per_cu and cfg["lds_bytes"] > 64 * 1024, cfg
-    assert cfg["team"]                                       # B <= number of CUs: the policy picks the team form
+    policy_team = cfg["store"] == "compact" and cfg["threads"] == 1024      # 16-wave workgroup that owns its CU, B <= number of CUs
+    assert cfg["team"] == policy_team
     c200 = ops.gls_describe_config(200, 256)
     assert c200["store"] == "compact" and c200["team"] and c200["threads"] == 1024 and c200["lds_bytes"] <= 160 * 1024
     rng = np.random.default_rng(4000 + n)
@@ -183,7 +184,7 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
     with ops.gls_team_mode(team):
-        assert ops.gls_describe_config(n, B, penalty_bits=bits)["team"] == (team != 0)
+        assert ops.gls_describe_config(n, B, penalty_bits=bits)["team"] == (team != 0 and policy_team)
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
                         trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
         plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
