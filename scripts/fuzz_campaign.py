@@ -30,11 +30,12 @@ def main():
     ap.add_argument("--max_n", type=int, default=130)
     args = ap.parse_args()
     master = np.random.default_rng(args.seed)
-    bad, moves, t0 = [], 0, time.time()
+    bad, moves, teamed, t0 = [], 0, 0, time.time()
     for ci in range(args.cases):
         c = dict(n=int(master.integers(args.min_n, args.max_n + 1)), kind=str(master.choice(["euclid", "lattice", "noisy"])),
                  pm=int(master.choice([1, 5, 20, 30])), fi=bool(master.integers(0, 2)), K=int(master.integers(1, args.max_k + 1)),
-                 bits=int(master.choice([0, 16, 32, -1, -2])), guides=int(master.integers(1, 3)), seed=int(master.integers(1 << 30)))
+                 bits=int(master.choice([0, 16, 32, -1, -2])), guides=int(master.integers(1, 3)), seed=int(master.integers(1 << 30)),
+                 team=int(master.integers(0, 2)))                 # form of the perturbation phase (1 = team wherever it exists)
         rng = np.random.default_rng(c["seed"])
         n, B = c["n"], 3
         Ds, Gs = zip(*[make_case(rng, n, c["kind"]) for _ in range(B)])
@@ -44,8 +45,10 @@ def main():
         gd = torch.from_numpy(np.ascontiguousarray(guides)).cuda()
         init = ops.nearest_neighbor(gd[0].contiguous())
         cost = ops.tour_cost(init, d)
-        r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
-                        trace_cap=1 << 15, want_penalty=True, penalty_bits=c["bits"])
+        with ops.gls_team_mode(c["team"]):
+            teamed += int(ops.gls_describe_config(n, B, c["bits"])["team"])
+            r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
+                            trace_cap=1 << 15, want_penalty=True, penalty_bits=c["bits"])
         init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
         for b in range(B):
             o = go.guided_local_search(D[b], guides[:, b], init_h[b], cost_h[b], perturbation_moves=c["pm"],
@@ -60,7 +63,8 @@ def main():
             moves += L
             if not ok:
                 bad.append((ci, b, c))
-    print(f"{args.cases} cases x 3 instances, {moves} accepted moves compared, {len(bad)} mismatches, {time.time() - t0:.0f} s")
+    print(f"{args.cases} cases x 3 instances ({teamed} cases on the team form of the perturbation phase), {moves} accepted moves "
+          f"compared, {len(bad)} mismatches, {time.time() - t0:.0f} s")
     for item in bad[:10]:
         print("MISMATCH", item)
     sys.exit(1 if bad else 0)

@@ -30,6 +30,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time_limit", type=float, default=10.0)
     ap.add_argument("--sample", type=int, default=16)
+    ap.add_argument("--n", "--tsp_n", dest="n", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=1024, help="TSP200: 256 (one 16-wave workgroup per CU, team form of the perturbation phase)")
     ap.add_argument("--guide", choices=["weight", "regret_pred"], default="weight",
                     help="regret_pred: the guide matrix is the GPU forward of the synthetic model; the oracle gets the same matrix")
     args = ap.parse_args()
@@ -37,7 +39,7 @@ def main():
     from gnngls_amd.synthetic import random_instances
     from oracle import gls_oracle as go
     go.build()
-    n, B = 100, 1024
+    n, B = args.n, args.batch
     D_host, _ = random_instances(np.random.default_rng(2024), B, n)
     D = torch.from_numpy(D_host).cuda()
     G = D
@@ -61,7 +63,7 @@ def main():
         same = (r.best_tour[b].cpu().tolist() == tour
                 and np.float64(r.best_cost[b].item()).view(np.uint64) == np.float64(c).view(np.uint64))
         bad += not same
-    print(f"TSP100 x {B}, guide {args.guide}, {args.time_limit:g} s on the GPU: {iters.mean():.0f} outer iterations per instance; {args.sample} sampled "
+    print(f"TSP{n} x {B} ({ops.gls_describe_config(n, B)}), guide {args.guide}, {args.time_limit:g} s on the GPU: {iters.mean():.0f} outer iterations per instance; {args.sample} sampled "
           f"instances re-run on the CPU oracle for their own iteration counts ({iters[pick].min()}..{iters[pick].max()}) in "
           f"{time.time() - t0:.0f} s: {args.sample - bad} identical best tours and costs, {bad} mismatches")
     sys.exit(1 if bad else 0)
