@@ -1593,9 +1593,13 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 #endif
     }
 #ifdef GLS_STAMPS
-    if (TEAM && A.stamps && lane == 0) {      // second region of the stamp buffer: [B,16] per-wavefront unit cycles of the team rounds
+    if (A.stamps && lane == 0 && wave < 16) {
+        // further regions of the stamp buffer, [B,16] each, one slot per wavefront: unit cycles of the team rounds, then the
+        // descent's scan cycles and its arg-min + wait cycles
         long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
-        if (wave < 16) o2[wave] = st.acc[12];
+        if (TEAM) o2[wave] = st.acc[12];
+        o2[(size_t)A.B * 16 + wave] = st.acc[8];
+        o2[(size_t)A.B * 32 + wave] = st.acc[9];
     }
     // per-wavefront view of the descent (waves 1..3; wave 0 is slots 8 / 9) and where the hardware placed each wave:
     // slot 12 = wave 1's arg-min + wait, slots 13..15 = scan cycles of waves 1..3, slot 7 = (SIMD id + 1) << 8 wave

@@ -202,8 +202,9 @@ int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits);
 
 /* 1 if gnngls_gls_run would run the perturbation phase of this (n, B, penalty_bits) on ALL wavefronts of the workgroup
  * (the "team" form: the four one-to-all scans of a penalty step, algorithms.py:167-174, evaluated concurrently and consumed
- * in the reference's order -- chosen when every workgroup of the batch owns a CU, B <= number of CUs), 0 if on wavefront 0
- * only.  Same results either way (bit-exact); this only reports the policy. */
+ * in the reference's order), 0 if on wavefront 0 only.  The policy picks it for 16-wave workgroups that own a CU by their
+ * LDS footprint (compact store, n >= 144: TSP200) when B <= number of CUs -- where it was measured faster.  Same results
+ * either way (bit-exact); this only reports the policy. */
 int gnngls_gls_uses_team(int n, int B, int penalty_bits);
 
 /* Experiment / test hook: -1 = the policy above (default), 0 = never use the team form, 1 = use it wherever it exists

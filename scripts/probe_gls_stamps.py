@@ -26,7 +26,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "model":          # the bench's guide: r
 # the stamp sink is a side buffer registered through the debug hook of the C ABI;
 # trace_cap=0 = the throughput path (trace-free kernel instantiation, deferred tour_cost)
 from gnngls_amd import _lib
-stamps = torch.zeros((2 * B, 16), dtype=torch.int64, device="cuda")
+stamps = torch.zeros((4 * B, 16), dtype=torch.int64, device="cuda")
 _lib.check(_lib.load().gnngls_debug_set_stamp_buffer(_lib.ptr(stamps)))
 tc = int(os.environ.get("TRACE_CAP", "0"))
 _lib.check(_lib.load().gnngls_debug_set_gls_team(int(os.environ.get("TEAM", "-1"))))
@@ -34,7 +34,9 @@ print("config", ops.gls_describe_config(n, B, int(os.environ.get('BITS', '0'))))
 r = ops.gls_run(D, g, init, cost, penalty_bits=int(os.environ.get('BITS', '0')), perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
 torch.cuda.synchronize()
-per_wave = stamps[B:].double().mean(0).cpu().numpy()
+per_wave = stamps[B:2 * B].double().mean(0).cpu().numpy()
+scan_w = stamps[2 * B:3 * B].double().mean(0).cpu().numpy()
+wait_w = stamps[3 * B:].double().mean(0).cpu().numpy()
 stamps = stamps[:B]
 raw = stamps.cpu().numpy()
 st = stamps.double().mean(0).cpu().numpy()
@@ -58,3 +60,5 @@ print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.to
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
 if per_wave.sum() > 0:
     print("team rounds: unit cycles per outer iteration, per wavefront:", " ".join(f"{v / it:.0f}" for v in per_wave))
+print("descent, per wavefront, cycles per scan: scan      ", " ".join(f"{v / sc:.0f}" for v in scan_w))
+print("descent, per wavefront, cycles per scan: arg-min+wait", " ".join(f"{v / sc:.0f}" for v in wait_w))
