@@ -22,7 +22,9 @@
 //     wavefront it is three 32-bit DPP min-reductions, no LDS-crossbar shuffles;
 //   * the perturbation phase (O(n) work per step, long serial chain) runs in wavefront 0 only, so
 //     it needs no workgroup barriers; the other wavefronts park on one barrier; utilities of the
-//     tour edges are cached in registers, guided evaluations issue all their loads up front;
+//     tour edges are cached in registers, guided evaluations issue all their loads up front
+//     (16-wave workgroups that own their CU -- TSP200 -- run it on ALL wavefronts instead: the four
+//     one-to-all scans of a penalty step at once, consumed in the reference's order: team_perturbation);
 //   * all floating point is fp64 with contraction OFF: the guided matrix `D + k*P`
 //     (algorithms.py:164) must round twice, np.isclose (operators.py:42) is evaluated literally.
 //
