@@ -338,6 +338,30 @@ def test_gls_long_run_compact_store_vs_oracle(ops):
         assert np.array_equal(r.penalty[b].cpu().numpy(), o["penalty"]) and o["penalty"].max() >= 5
 
 
+@pytest.mark.parametrize("team", [0, 1], ids=["serial", "team"])
+def test_watchdog_stops_an_endless_perturbation_phase(ops, team):
+    """`while moves < perturbation_moves` (algorithms.py:151) ignores the clock: with an unreachable move count the phase never
+    ends by itself.  The device watchdog is checked inside the phase too (every 64 penalty steps), in both forms: the run
+    comes back with status WATCHDOG, valid tours and the cost of the best tour, instead of hanging."""
+    import time
+    n, B = 150, 3
+    D, _ = random_instances(np.random.default_rng(8), B, n)
+    d = dev(D, torch.float64)
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    with ops.gls_team_mode(team):
+        assert ops.gls_describe_config(n, B, penalty_bits=-2)["team"] == bool(team)
+        t0 = time.time()
+        r = ops.gls_run(d, d[None].contiguous(), init, cost, perturbation_moves=2 ** 30, max_outer_iters=5, watchdog_s=0.3,
+                        penalty_bits=-2)
+        torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0
+    assert (r.status == ops.STATUS_WATCHDOG).all()
+    bt = r.best_tour.cpu().numpy()
+    assert (np.sort(bt[:, :-1], axis=1) == np.arange(n)[None]).all() and (bt[:, -1] == 0).all()
+    assert torch.allclose(ops.tour_cost(r.best_tour, d), r.best_cost, rtol=1e-12, atol=0)
+
+
 def test_empty_batches_are_noops(ops):
     d = torch.zeros((0, 5, 5), dtype=torch.float64, device="cuda")
     t = torch.zeros((0, 6), dtype=torch.int32, device="cuda")
