@@ -40,6 +40,7 @@ SIGNATURES = {
     "gnngls_debug_set_stamp_buffer": [_vp],
     "gnngls_debug_set_gls_threads": [_int],
     "gnngls_debug_set_gls_team": [_int],
+    "gnngls_debug_set_gls_prune": [_int],
     "gnngls_gls_uses_team": [_int, _int, _int],
     "gnngls_gls_waves_per_simd": [_int, _int, _int],
     "gnngls_profile_enable": [_int],

@@ -57,6 +57,7 @@ struct ProfScope {
 };
 
 int g_pen16_limit = 65535;
+std::atomic<int> g_prune_mode{-1};     // -1 / 1 = pruned descent scans where they exist, 0 = full scans (experiments / tests)
 std::atomic<int> g_team_mode{-1};      // -1 = policy (gls_config), 0 = never, 1 = wherever the team form exists (experiments / tests)
 long long *g_stamp_buffer = nullptr;
 
@@ -74,7 +75,7 @@ int num_cus() {
 
 // Storage configuration of the persistent search kernel for instances of n nodes: the one with the
 // most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
-struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; bool team = false; };
+struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; bool team = false; bool prune = false; };
 
 GlsConfig gls_config_store(int n, int requested_bits, int batch);
 
@@ -93,6 +94,18 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
         // the re-evaluation after a move cost more than the few passes they save (profiles/r03_experiments/README.md)
         const bool pays = batch > 0 && batch <= num_cus() && c.store == gnngls::GLS_STORE_COMPACT && c.threads == 1024;
         if (lds <= kLdsPerCU && (mode == 1 || pays)) { c.team = true; c.lds = lds; }
+    }
+    return c;
+}
+
+// + the pruned descent scans (nearest-neighbour lists; 4-slot instantiations, n >= 128) where the position table still fits
+GlsConfig gls_config_run(int n, int requested_bits, int batch, bool first_improvement) {
+    GlsConfig c = gls_config(n, requested_bits, batch);
+    if (g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement) &&
+        (c.wps == 4 || c.store == gnngls::GLS_STORE_TRI)) {
+        const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, c.team, true);
+        const int per_cu = (int)(kLdsPerCU / (lds ? lds : 1));
+        if (lds <= kLdsPerCU && per_cu >= c.per_cu) { c.prune = true; c.lds = lds; }      // never at the price of residency
     }
     return c;
 }
@@ -163,7 +176,7 @@ int gnngls_gls_resident_capacity(int n) {
 int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu) {
     if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
         return fail(GNNGLS_ERR_ARG, "gls_describe_config: bad argument");
-    const GlsConfig c = gls_config(n, penalty_bits, B);
+    const GlsConfig c = gls_config_run(n, penalty_bits, B, false);     // as a best-improvement run would be launched
     if (c.lds > kLdsPerCU)
         return fail(GNNGLS_ERR_UNSUPPORTED, "gls_describe_config: n=%d needs %zu B of LDS for tours and edge lengths (> 160 KiB)", n, c.lds);
     if (store) *store = c.store * 100 + (c.store == gnngls::GLS_STORE_TRI ? c.penalty_bits : 0);
@@ -257,7 +270,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.imp_cost = imp_cost; A.imp_time = imp_time; A.imp_iter = (long long *)imp_iter; A.imp_cap = imp_cap; A.imp_len = imp_len;
     A.stamps = g_stamp_buffer;
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
-    const GlsConfig cfg = gls_config(n, penalty_bits, B);
+    const GlsConfig cfg = gls_config_run(n, penalty_bits, B, first_improvement != 0);
     if (cfg.lds > kLdsPerCU)     // even the global-memory store keeps tours and per-position edge lengths in LDS
         return fail(GNNGLS_ERR_UNSUPPORTED, "gls_run: n=%d needs %zu B of LDS for tours and edge lengths (> 160 KiB)", n, cfg.lds);
     int32_t *ws = nullptr;
@@ -275,10 +288,23 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
         A.pen_ws = ws;
     }
     hipError_t e;
+    void *nl = nullptr;          // nearest-neighbour lists of the pruned descent scans
+    if (cfg.prune) {
+        const size_t entries = (size_t)B * n * gnngls::kNeighborListLen;
+        e = hipMallocAsync(&nl, entries * sizeof(double) + (size_t)B * sizeof(int32_t) + entries, st);
+        if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour-list alloc"); }
+        double *nl_d = (double *)nl;
+        int32_t *ok = (int32_t *)(nl_d + entries);
+        uint8_t *nl_id = (uint8_t *)(ok + B);
+        e = gnngls::launch_neighbor_lists(D, B, n, nl_id, nl_d, ok, st);
+        if (e != hipSuccess) { (void)hipFreeAsync(nl, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour lists"); }
+        A.nl_id = nl_id; A.nl_d = nl_d; A.prune_ok = ok;
+    }
     {
         ProfScope ps(GNNGLS_PROF_GLS, st);
         e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, cfg.wps, cfg.team, first_improvement != 0, st);
     }
+    if (nl) (void)hipFreeAsync(nl, st);
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
 }
@@ -617,6 +643,12 @@ extern "C" {
 int gnngls_debug_set_penalty16_limit(int limit) {
     if (limit < 1 || limit > 65535) return fail(GNNGLS_ERR_ARG, "penalty16 limit must be in 1..65535");
     g_pen16_limit = limit;
+    return GNNGLS_OK;
+}
+
+int gnngls_debug_set_gls_prune(int mode) {
+    if (mode < -1 || mode > 1) return fail(GNNGLS_ERR_ARG, "gls prune mode must be -1 (default: on), 0 (full scans) or 1 (on)");
+    g_prune_mode.store(mode, std::memory_order_relaxed);
     return GNNGLS_OK;
 }
 

@@ -36,10 +36,15 @@ struct GlsArgs {
     long long *imp_iter;       // [B,imp_cap] completed outer iterations at that moment, or NULL
     int imp_cap;
     int32_t *imp_len;          // [B] number of improvements (may exceed imp_cap); written by the kernel
+    // pruned descent scans (best improvement, symmetric stores, n >= 128): 32 nearest neighbours per node, see
+    // neighbor_lists_kernel; NULL = full scans
+    const uint8_t *nl_id;      // [B,n,32]
+    const double *nl_d;        // [B,n,32]
+    const int32_t *prune_ok;   // [B] 1 = the instance's matrix is within the magnitude bound of the pruning argument
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
-size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false);
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false, bool prune = false);
 int gls_block_threads(int n, int store);
 void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 // resident wavefronts per SIMD (= register budget) of the kernel instantiation for this configuration: 4 or 8 for the
@@ -50,6 +55,9 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
 bool gls_team_supported(int store, int penalty_bits, int wps, int n);
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
+constexpr int kNeighborListLen = 32;
+bool gls_prune_supported(int store, int n, bool first_improvement);
+hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok, hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
                             bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,

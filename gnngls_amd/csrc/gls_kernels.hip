@@ -46,6 +46,9 @@ namespace gnngls {
 #ifndef GLS_PERTURB_PRIO
 #define GLS_PERTURB_PRIO 3           // s_setprio of the wavefront that carries the perturbation phase
 #endif
+#ifndef GLS_PRUNE_TWO_OPT_ONLY
+#define GLS_PRUNE_TWO_OPT_ONLY 0     // experiments: 1 = only the 2-opt descent scan is pruned
+#endif
 #ifndef GLS_TEAM_SCANS
 #define GLS_TEAM_SCANS 4             // team form: one-to-all scans evaluated per round (4 = both endpoints, 2 = one endpoint, 1)
 #endif
@@ -64,7 +67,7 @@ constexpr int kGuidePassesMax = 4;   // register-cached guide values cover n <= 
 // a side buffer that nothing else reads.  The shipped library is built without it.
 struct Stamps {
 #ifdef GLS_STAMPS
-    long long acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long t0 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
     __device__ __forceinline__ void end(int i) { const long long n = clock64(); acc[i] += n - t0; t0 = n; }
@@ -875,6 +878,200 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     }
 }
 
+// ---- pruned a2a scans (best improvement, symmetric stores, n >= 130: the 4-slot instantiations) -----------------------
+// The descent needs, per scan, the lexicographic minimum of (delta, i, j) over the moves that qualify (delta < 0 and not
+// np.isclose(0, delta), operators.py:42).  Any SUPERSET of the qualifying moves gives the same minimum, and most of the
+// O(n^2) moves of a tour that is a few moves away from a local optimum cannot qualify:
+//   2-opt   delta = ((D[a,c] + D[b,d]) - D[a,b]) - D[c,d] < 0 needs D[a,c] < D[a,b] or D[b,d] < D[c,d] (exactly so in real
+//           arithmetic; the three roundings move delta by < 1.4e-15 max|D| and a qualifying delta is below -1e-8, so with
+//           max|D| <= 1e6 -- checked once per instance by neighbor_lists_kernel, else the full scans run -- no qualifying
+//           move is lost): only pairs (x, y) with y closer to x than one of x's two tour neighbours;
+//   relocate delta = ((base_i - D[d,e]) + D[d,b]) + D[b,e] with T = fl(D[d,e] - base_i): if 2 D[d,b] >= T and 2 D[b,e] >= T
+//           then fl(-T + D[d,b]) >= -T/2 and the last sum is >= 0 (rounding is monotone, T/2 is exact): a qualifying
+//           move has an endpoint y of its target edge with 2 D[b,y] < T, for ANY symmetric matrix (no triangle inequality).
+// Every node has a list of its kNL = 32 nearest nodes, ascending (id + distance, built once per instance by
+// neighbor_lists_kernel into global memory).  A thread owns ONE list entry of one tour row: 16 lanes per row (position
+// p, node x = t[p]), four rows per wavefront, the rows' distances arrive as one coalesced 128-byte read each.  Entries that
+// pass the row's threshold look their node's position up and the few surviving candidates (~1000 / ~250 of 19,503 /
+// 39,204 moves per scan at n = 200) are evaluated with the reference's operand order -- same operands, same bits as the
+// full scans -- all at once under the exec mask.  A row whose 16th entry still passes takes entries 17..32 in a second
+// step; a row whose 32nd entry passes is evaluated in full by its wavefront (rare).  Tour-edge lengths are bounded by
+// Lmax (an upper bound of Ef[], kept by local_search_dev).
+constexpr int kNL = 32;
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
+                                                        const uint8_t *nl_id, const double *nl_d, int n,
+                                                        int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
+    const PlainDist<S> f{s};
+    const int tasks = 16 * (n - 1);
+    const int rowbit = (lane & 48) + 15;                     // lane that holds entry 15 / 31 of this lane's row
+    for (int task0 = 0; task0 < tasks; task0 += nthr) {      // wave-uniform trip count; a wavefront's tasks are whole rows
+        const int task = task0 + tid;
+        const bool live = task < tasks;
+        const int p = 1 + (live ? task >> 4 : 0), m = task & 15;
+        const int x = t[p], xm = t[p - 1], xp = t[p + 1];
+        const double ep = Ef[p], es = Ef[p + 1];             // D[x, t[p-1]], D[x, t[p+1]]
+        const double thr = ep > es ? ep : es;
+        bool more = live;                                    // the row may hold candidates among its next 16 list entries
+#pragma unroll 1
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            const size_t e = (size_t)x * kNL + lvl * 16 + m;
+            const int y = nl_id[e];
+            const double d = nl_d[e];
+            const bool act = more && d < thr;
+            const int q = pos[y];
+            // y = t[q]: (a, c) = (x, y) of the move (i, j) = (p, q) if q >= p + 2; (d, b) = (x, y) of (q + 1, p + 1) if q <= p - 2
+            const bool ca = act && d < ep && q >= p + 2;
+            const bool cb = act && d < es && q <= p - 2 && p <= n - 2;
+            if (ca || cb) {
+                const int o2 = t[ca ? q - 1 : q + 1];
+                const double e2 = Ef[ca ? q : q + 1];
+                const double dpair = s.dist(ca ? xm : xp, o2);           // D[b,d] (A) / D[a,c] (B)
+                double delta = d + dpair;                                // operators.py:25-28 (the sum of two terms commutes)
+                delta = delta - (ca ? ep : e2);                          // - D[a,b]
+                delta = delta - (ca ? e2 : es);                          // - D[c,d]
+                consider<false>(delta, ca ? make_key(p, q) : make_key(q + 1, p + 1), bd, bk);
+            }
+            const unsigned long long need = __ballot(act && m == 15);    // rows whose last entry of this level still passes
+            more = (need >> rowbit) & 1ull;
+            if (!need) break;
+        }
+        // all 32 entries below the row's threshold: every move that has x as `a` (row p) or as `d` (column p + 1)
+        unsigned long long om = __ballot(more && m == 15);
+#ifdef GLS_STAMPS
+        if (dbg && lane == 0) { dbg[0] += __popcll(om); dbg[2] += 1; }
+#endif
+        while (om) {
+            const int src = __ffsll((long long)om) - 1;
+            om &= om - 1;
+            const int pr = __builtin_amdgcn_readlane(p, src);
+            for (int j = pr + 2 + lane; j <= n - 1; j += kWave) consider<false>(two_opt_cost(t, f, pr, j), make_key(pr, j), bd, bk);
+            if (pr + 1 <= n - 1)
+                for (int i = 1 + lane; i <= pr - 1; i += kWave) consider<false>(two_opt_cost(t, f, i, pr + 1), make_key(i, pr + 1), bd, bk);
+        }
+    }
+}
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
+                                                         const uint8_t *nl_id, const double *nl_d, int n, double Lcap,
+                                                         const int *longk, int nlong,
+                                                         int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
+    const PlainDist<S> f{s};
+    const int tasks = 16 * (n - 1);
+    const int rowbit = (lane & 48) + 15;
+    for (int task0 = 0; task0 < tasks; task0 += nthr) {
+        const int task = task0 + tid;
+        const bool live = task < tasks;
+        const int p = 1 + (live ? task >> 4 : 0), m = task & 15;
+        const int b = t[p];
+        double base = -Ef[p];                                    // -D[a,b]          (operators.py:97-99, left to right)
+        base = base - Ef[p + 1];                                 // -D[b,c]
+        base = base + s.dist(t[p - 1], t[p + 1]);                // +D[a,c]
+        // Target edges no longer than Lcap: fl(D[d,e] - base) <= Tmax, so an endpoint of a qualifying move's target edge has
+        // 2 D[b,y] < Tmax and sits in the list prefix walked below.  The (few) longer tour edges are in longk[] and every
+        // row evaluates them directly: a single long edge left by the perturbation phase would otherwise push every row's
+        // threshold beyond its list (12.9 of 16 rows per wavefront overflowed with the tour's maximum edge as the bound).
+        const double Tmax = Lcap - base;
+        if (live && m < nlong) {
+            const int k = longk[m];
+            if ((unsigned)(k - p + 2) > 2u) {
+                double delta = base - Ef[k + 1];                 // operators.py:100-102, left to right
+                delta = delta + s.dist(t[k], b);                 // +D[d,b]
+                delta = delta + s.dist(b, t[k + 1]);             // +D[b,e]
+                consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
+            }
+        }
+        bool more = live;
+#pragma unroll 1
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            const size_t e = (size_t)b * kNL + lvl * 16 + m;
+            const int y = nl_id[e];
+            const double d = nl_d[e];
+            const double two_d = d + d;
+            const bool act = more && two_d < Tmax;
+            const int q = pos[y];
+            // y = t[q] is d of target edge k1 = q and e of target edge k2 = q - 1 (the depot closes the tour: e = t[n])
+            const int k1 = q, k2 = y == 0 ? n - 1 : q - 1;
+            const double e1 = Ef[k1 + 1], e2 = Ef[k2 + 1];       // D[d,e]
+            // valid targets of row p: k not in {p-2, p-1, p} (operators.py:133-136: i - j == 1 <=> k = p - 2)
+            const bool c1 = act && (unsigned)(k1 - p + 2) > 2u && two_d < e1 - base;
+            const bool c2 = act && (unsigned)(k2 - p + 2) > 2u && two_d < e2 - base;
+            if (c1) {
+                double delta = base - e1;                        // operators.py:100-102, left to right
+                delta = delta + d;                               // +D[d,b]
+                delta = delta + s.dist(b, t[k1 + 1]);            // +D[b,e]
+                consider<false>(delta, make_key(p, k1 < p ? k1 + 1 : k1), bd, bk);
+            }
+            if (c2) {
+                double delta = base - e2;
+                delta = delta + s.dist(t[k2], b);                // +D[d,b]
+                delta = delta + d;                               // +D[b,e]
+                consider<false>(delta, make_key(p, k2 < p ? k2 + 1 : k2), bd, bk);
+            }
+            const unsigned long long need = __ballot(act && m == 15);
+            more = (need >> rowbit) & 1ull;
+            if (!need) break;
+        }
+        unsigned long long om = __ballot(more && m == 15);
+#ifdef GLS_STAMPS
+        if (dbg && lane == 0) { dbg[1] += __popcll(om); dbg[3] += 1; }
+#endif
+        while (om) {                                             // whole row i = pr (operators.py:133-136)
+            const int src = __ffsll((long long)om) - 1;
+            om &= om - 1;
+            const int pr = __builtin_amdgcn_readlane(p, src);
+            for (int j = 1 + lane; j <= n - 1; j += kWave) {
+                if (j == pr || pr - j == 1) continue;
+                consider<false>(relocate_cost(t, f, pr, j), make_key(pr, j), bd, bk);
+            }
+        }
+    }
+}
+
+// wave-wide maximum of doubles (order-preserving integer image, two 32-bit DPP reductions); result uniform
+__device__ __forceinline__ unsigned long long wave_max_sortable(unsigned long long sk) {
+    const unsigned hi = ~(unsigned)(sk >> 32), lo = ~(unsigned)sk;
+    const unsigned mhi = wave_umin(hi);
+    const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
+    return ~(((unsigned long long)mhi << 32) | mlo);
+}
+// upper bound of the tour-edge lengths Ef[1..n] for the pruned relocate scan, as an LDS slot in the order-preserving
+// image: aliases an exchange slot of block_reduce_best that the best-improvement descent never touches
+__device__ __forceinline__ unsigned long long *lmax_slot(Ctl *ctl) { return reinterpret_cast<unsigned long long *>(&ctl->red_d[1][7]); }
+__device__ __forceinline__ void lmax_raise(Ctl *ctl, double v) {
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+    __hip_atomic_fetch_max((lds_u64_t *)lmax_slot(ctl), sortable(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Nearest-neighbour lists of the pruned scans: one workgroup per instance, thread x selects the kNL nearest nodes of x by
+// (D[x,y], y) ascending.  prune_ok[b] = every entry finite and |D| <= 1e6 (see above).
+__global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok) {
+    const int b = blockIdx.x;
+    const double *Dg = D + (size_t)b * n * n;
+    int bad = 0;
+    for (int x = threadIdx.x; x < n; x += blockDim.x) {
+        const double *row = Dg + (size_t)x * n;
+        double last_d = -__builtin_inf(); int last_y = -1;
+        for (int m = 0; m < kNL; ++m) {
+            double best = __builtin_inf(); int by = -1;
+            for (int y = 0; y < n; ++y) {
+                if (y == x) continue;
+                const double v = row[y];
+                if (m == 0 && !(fabs(v) <= 1e6)) bad = 1;        // also catches NaN / inf
+                if ((v > last_d || (v == last_d && y > last_y)) && (by < 0 || v < best)) { best = v; by = y; }
+            }
+            const size_t o = ((size_t)b * n + x) * kNL + m;
+            nl_id[o] = (uint8_t)(by < 0 ? 0 : by);
+            nl_d[o] = best;
+            last_d = best; last_y = by;
+        }
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) prune_ok[b] = !bad;
+}
+
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
 template <class F, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a(const TT *t, const F &f, int n, int i,
@@ -956,19 +1153,23 @@ __device__ __forceinline__ void scan_relocate_o2a_guided(const S &s, double k, c
 }
 
 // new tour + edge arrays in one pass; caller synchronises afterwards.
-// pos (descent with node-indexed relocate lanes): node -> position table, kept current here
+// pos (descent with node-indexed relocate lanes): node -> position table, kept current here.
+// ppos / ctl / Lmax (descent with pruned scans): the same table in the tour's element type and the upper bound of Ef[].
 template <class S, class TT>
 __device__ __forceinline__ void apply_move(const S &s, const TT *told, TT *tnew, double *Ef, double *Eb,
                                            int n, int op, int i, int j, int tid, int nthr, bool want_edges,
-                                           uint8_t *pos = nullptr) {
+                                           uint8_t *pos = nullptr, TT *ppos = nullptr, Ctl *ctl = nullptr, double Lmax = 0.0) {
     for (int p = tid; p <= n; p += nthr) {
         int np = told[move_src(op, p, i, j)];
         tnew[p] = (TT)np;
         if (pos && p < n) pos[np] = (uint8_t)p;
+        if (ppos && p < n) ppos[np] = (TT)p;
         if (want_edges && p >= 1) {
             int nq = told[move_src(op, p - 1, i, j)];
-            Ef[p] = s.dist(nq, np);
+            const double e = s.dist(nq, np);
+            Ef[p] = e;
             if (!S::kSymmetric) Eb[p] = s.dist(np, nq);
+            if (ppos && e > Lmax) lmax_raise(ctl, e);
         }
     }
 }
@@ -1250,11 +1451,24 @@ struct Trace<false> {
     __device__ __forceinline__ void push(double) { len++; }
 };
 
+// neighbour lists of the pruned descent scans for this instance (on = false: the full scans run); ppos = node -> position
+struct PruneCtx {
+    const uint8_t *id; const double *d; bool on;
+};
+
 template <class S, bool FI, int GP, class TT, class TRC>
-__device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
-                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st) {
+__device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
+                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st,
+                                 TT *ppos, const PruneCtx &pc) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
+    constexpr bool kCanPrune = !FI && S::kSymmetric && GP == 4;      // compiled into the 4-slot instantiations (n >= 128) only
+    const bool prune = kCanPrune && pc.on;
+    double Lmax = 0.0;
+    if (prune) {
+        if (tid == 0) *lmax_slot(ctl) = 0ull;                        // below the image of every double
+        __syncthreads();
+    }
     // node -> position table of the node-indexed relocate scan: n <= 104 bytes in the exchange slots of Ctl that the
     // best-improvement descent never touches (its LDS-atomic arg-min uses the first 24 bytes of red_d and 12 of red_k;
     // the compact store's 40 KiB at n = 100 have no other byte to spare)
@@ -1264,7 +1478,29 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
                        ? reinterpret_cast<uint8_t *>(&ctl->red_d[0][3]) : nullptr;
     build_edges(s, t, Ef, Eb, n, tid, nthr);
     if (pos) for (int p = tid; p < n; p += nthr) pos[t[p]] = (uint8_t)p;
+    if constexpr (kCanPrune) {
+        if (prune) {         // node -> position (the depot keeps position 0) and the maximum tour-edge length
+            unsigned long long mine = 0ull;
+            for (int p = tid; p <= n; p += nthr) {
+                if (p < n) ppos[t[p]] = (TT)p;
+                if (p >= 1) { const unsigned long long sk = sortable(s.dist(t[p - 1], t[p])); mine = sk > mine ? sk : mine; }
+            }
+            mine = wave_max_sortable(mine);
+            if (lane == 0 && mine != 0ull) {
+                typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+                __hip_atomic_fetch_max((lds_u64_t *)lmax_slot(ctl), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
     __syncthreads();
+    if (prune) Lmax = unsortable(*lmax_slot(ctl));
+    // pruned relocate scan: tour edges longer than Lcap (three mean edge lengths of the tour the descent starts from) are
+    // listed per scan (at most kLongCap, else that scan runs unpruned) in exchange slots the descent does not use
+    constexpr int kLongCap = 16;
+    const double Lcap = 3.0 * cur_cost / (double)n;
+    int *longk = reinterpret_cast<int *>(&ctl->red_d[0][3]);     // 16 ints: bytes 24 .. 87 of red_d
+    int *nlong_slot = &ctl->red_k[1][0];
+    (void)Lmax;
     bool improved = true;
     while (improved) {                                               // algorithms.py:116
         improved = false;
@@ -1272,13 +1508,38 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
             bool lean = false;
+            if constexpr (kCanPrune) {
+                int nlong = 0;
+                if (prune && op == 1 && !GLS_PRUNE_TWO_OPT_ONLY) {
+                    if (tid == 0) *nlong_slot = 0;
+                    __syncthreads();
+                    for (int q = 1 + tid; q <= n; q += nthr)
+                        if (Ef[q] > Lcap) {
+                            typedef __attribute__((address_space(3))) int lds_i32_t;
+                            const int slot = __hip_atomic_fetch_add((lds_i32_t *)nlong_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (slot < kLongCap) longk[slot] = q - 1;            // target edge k = (t[k], t[k+1]), Ef[k+1] its length
+                        }
+                    __syncthreads();
+                    nlong = *nlong_slot;
+                }
+                if (prune && (op == 0 || (!GLS_PRUNE_TWO_OPT_ONLY && nlong <= kLongCap))) {
+#ifdef GLS_STAMPS
+                    long long *dbg = &st.acc[16];            // overflow rows (2-opt, relocate), wave-passes (2-opt, relocate)
+#else
+                    long long *dbg = nullptr;
+#endif
+                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, pc.d, n, tid, nthr, lane, bd, bk, dbg);
+                    else         scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, pc.d, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
+                    lean = true;
+                }
+            }
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
             // software-pipelining the uniform operands one step ahead costs registers: 9.6k at TSP100
             if constexpr (!FI && S::kSymmetric) {
                 // positions 0..n fit 2 (n <= 127) or 4 (n <= 255) register slots per lane; every block of 64 rows needs
                 // a wavefront of its own
                 // (GP = register slots of the perturbation phase = the same 2 / 4, chosen by the launcher from n)
-                if (nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
+                if (!lean && nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
                     if (op == 0) scan_two_opt_a2a_lean<GP, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                     else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
                     lean = true;
@@ -1301,10 +1562,11 @@ __device__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
-                apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos);
+                apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos, prune ? ppos : nullptr, ctl, Lmax);
                 TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();
+                if (prune) Lmax = unsortable(*lmax_slot(ctl));
                 STAMP_END(10);   // move application + barrier
             }
         }
@@ -1339,6 +1601,8 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     TT *t = reinterpret_cast<TT *>(smem + off);                off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
     TT *t2 = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
     TT *bt = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
+    TT *ppos = nullptr;                                        // node -> position table of the pruned descent scans
+    if (A.nl_id) { ppos = reinterpret_cast<TT *>(smem + off);  off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15); }
 
     S s;
     if constexpr (S::kSymmetric) {
@@ -1403,7 +1667,9 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
     if (!FI && nthr > kWave) { block_reduce_lds_init(ctl, tid); __syncthreads(); }
     STAMP_BEGIN();
-    local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);   // algorithms.py:142
+    PruneCtx pc{nullptr, nullptr, false};
+    if (A.nl_id && A.prune_ok[b]) { pc.id = A.nl_id + (size_t)b * n * kNL; pc.d = A.nl_d + (size_t)b * n * kNL; pc.on = true; }
+    local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
@@ -1558,7 +1824,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st);
+        local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -1600,6 +1866,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         // descent's scan cycles and its arg-min + wait cycles
         long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
         if (TEAM) o2[wave] = st.acc[12];
+        else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; }   // pruned-scan counters
         o2[(size_t)A.B * 16 + wave] = st.acc[8];
         o2[(size_t)A.B * 32 + wave] = st.acc[9];
     }
@@ -1720,11 +1987,12 @@ __global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------------------
-size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team) {
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team, bool prune) {
     auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t tour_elem = store == GLS_STORE_COMPACT ? 1 : 4;
     size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * tour_elem);
     if (team) off += r16(sizeof(TeamCtl));
+    if (prune) off += r16((size_t)(n + 1) * tour_elem);                 // node -> position table
     if (store == GLS_STORE_GLOBAL) off += r16((size_t)(n + 2) * 8);
     size_t ntri = (size_t)n * (n - 1) / 2;
     if (store != GLS_STORE_GLOBAL) off += r16(ntri * 8);
@@ -1813,7 +2081,7 @@ bool gls_team_supported(int store, int penalty_bits, int wps, int n) {
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream) {
     if (team && !gls_team_supported(store, penalty_bits, wps, A.n)) return hipErrorInvalidValue;
-    size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
+    size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team, A.nl_id != nullptr);
     if (store == GLS_STORE_COMPACT) {
         if (team) return launch_gls_f<TriDGlobalPF, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)
@@ -1827,6 +2095,18 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                         : launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     }
     return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+}
+
+// pruned descent scans exist in the 4-slot instantiations of the symmetric stores (n >= 128), best improvement only; the
+// lists must be full (n - 1 >= 32)
+bool gls_prune_supported(int store, int n, bool first_improvement) {
+    return store != GLS_STORE_GLOBAL && !first_improvement && n + 1 > 2 * kWave && n <= 255;
+}
+
+hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(neighbor_lists_kernel, dim3(B), dim3(256), 0, stream, D, n, nl_id, nl_d, prune_ok);
+    return hipGetLastError();
 }
 
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream) {

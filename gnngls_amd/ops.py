@@ -199,6 +199,22 @@ class gls_team_mode:
         return False
 
 
+class gls_prune_mode:
+    """Experiment / test hook (gnngls_debug_set_gls_prune): `with gls_prune_mode(0): ...` makes the descent evaluate every
+    move of its all-to-all scans instead of the pruned candidate sets (n >= 128).  Results are bit-identical either way."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        _lib.check(_lib.load().gnngls_debug_set_gls_prune(self.mode), "debug_set_gls_prune")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.load().gnngls_debug_set_gls_prune(-1), "debug_set_gls_prune")
+        return False
+
+
 def gls_describe_config(n, B=0, penalty_bits=0):
     """-> dict(store, threads, lds_bytes, per_cu, team, waves_per_simd): what gnngls_gls_run would use (host-side query)."""
     vals = [ctypes.c_int(0) for _ in range(4)]

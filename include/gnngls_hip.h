@@ -211,6 +211,12 @@ int gnngls_gls_uses_team(int n, int B, int penalty_bits);
  * (symmetric stores with 32-bit counters, n <= 255) whatever the batch size.  Never called by the product. */
 int gnngls_debug_set_gls_team(int mode);
 
+/* Experiment / test hook: 0 = the descent (algorithms.py:111-132) evaluates every move of an all-to-all scan; -1 / 1
+ * (default) = the pruned scans where they exist (best improvement, symmetric LDS stores, n >= 128, max |D| <= 1e6): per
+ * node a list of its 32 nearest nodes, only moves that can qualify are evaluated -- a superset of the qualifying moves,
+ * hence the same arg-min, bit-exact.  Never called by the product. */
+int gnngls_debug_set_gls_prune(int mode);
+
 /* Diagnostic hook: device buffer of 16 int64 per instance that a library built with -DGLS_STAMPS fills with
  * per-phase shader-cycle totals of gnngls_gls_run (scripts/probe_gls_stamps.py).  Ignored by normal builds. */
 int gnngls_debug_set_stamp_buffer(void *device_buffer);

@@ -20,6 +20,8 @@ team = int(sys.argv[7]) if len(sys.argv) > 7 else -1             # perturbation 
 from gnngls_amd import _lib  # noqa: E402
 _lib.check(_lib.load().gnngls_debug_set_gls_threads(threads))
 _lib.check(_lib.load().gnngls_debug_set_gls_team(team))
+import os  # noqa: E402
+_lib.check(_lib.load().gnngls_debug_set_gls_prune(int(os.environ.get("PRUNE", "-1"))))
 print("capacity", ops.gls_resident_capacity(n), ops.gls_describe_config(n, Bs[0], bits))
 for B in Bs:
     D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()

@@ -30,6 +30,7 @@ stamps = torch.zeros((4 * B, 16), dtype=torch.int64, device="cuda")
 _lib.check(_lib.load().gnngls_debug_set_stamp_buffer(_lib.ptr(stamps)))
 tc = int(os.environ.get("TRACE_CAP", "0"))
 _lib.check(_lib.load().gnngls_debug_set_gls_team(int(os.environ.get("TEAM", "-1"))))
+_lib.check(_lib.load().gnngls_debug_set_gls_prune(int(os.environ.get("PRUNE", "-1"))))
 print("config", ops.gls_describe_config(n, B, int(os.environ.get('BITS', '0'))))
 r = ops.gls_run(D, g, init, cost, penalty_bits=int(os.environ.get('BITS', '0')), perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0,
                 trace_cap=tc)
@@ -58,7 +59,10 @@ simd = [((raw[:, 7] >> (8 * w)) & 0xff) - 1 for w in range(4)]
 import collections
 print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.tolist() for x in simd])).most_common(6))
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
-if per_wave.sum() > 0:
+if int(os.environ.get("TEAM", "-1")) == 0 and per_wave[:4].sum() > 0:
+    print(f"pruned scans (wavefront 0): overflow rows per scan 2-opt {per_wave[0] / max(sc / 2, 1):.2f}, relocate {per_wave[1] / max(sc / 2, 1):.2f}; "
+          f"wave-passes per scan {per_wave[2] / max(sc / 2, 1):.2f} / {per_wave[3] / max(sc / 2, 1):.2f}")
+elif per_wave.sum() > 0:
     print("team rounds: unit cycles per outer iteration, per wavefront:", " ".join(f"{v / it:.0f}" for v in per_wave))
 print("descent, per wavefront, cycles per scan: scan      ", " ".join(f"{v / sc:.0f}" for v in scan_w))
 print("descent, per wavefront, cycles per scan: arg-min+wait", " ".join(f"{v / sc:.0f}" for v in wait_w))

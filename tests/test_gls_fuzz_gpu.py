@@ -42,15 +42,18 @@ for _ in range(14):
                       bits=int(_rng2.choice([0, -2])), guides=int(_rng2.integers(1, 3)), seed=int(_rng2.integers(1 << 30))))
 
 
-VARIANTS = {"serial": 0, "team": 1}     # form of the perturbation phase
+VARIANTS = {"serial": (0, 1), "team": (1, 1), "fullscan": (0, 0)}     # (team form of the perturbation phase, pruned descent scans)
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("c", CASES, ids=lambda c: f"n{c['n']}-{c['kind']}-pm{c['pm']}-fi{int(c['fi'])}-K{c['K']}-b{c['bits']}-g{c['guides']}")
 def test_fuzz_case(c, variant):
-    """Kernel variants, both bit-exact: `serial` = perturbation phase on wavefront 0 (what a device-filling batch runs);
-    `team` = on all wavefronts of the workgroup wherever that form exists (what the policy picks when B <= number of CUs)."""
-    team = VARIANTS[variant]
+    """Kernel variants, all bit-exact: `serial` = perturbation phase on wavefront 0 (what a device-filling batch runs);
+    `team` = on all wavefronts of the workgroup wherever that form exists; both with the pruned descent scans where those
+    exist (n >= 128, the default); `fullscan` = the descent evaluates every move of its scans."""
+    team, prune = VARIANTS[variant]
+    if not prune and c["n"] < 128:
+        pytest.skip("the pruned descent scans only exist for n >= 128: same kernel as the serial case")
     from gnngls_amd import ops
     from oracle import gls_oracle as go
     if team and c["bits"] == 16:
@@ -64,7 +67,7 @@ def test_fuzz_case(c, variant):
     gd = torch.from_numpy(np.ascontiguousarray(guides)).cuda()
     init = ops.nearest_neighbor(gd[0].contiguous())
     cost = ops.tour_cost(init, d)
-    with ops.gls_team_mode(team):
+    with ops.gls_team_mode(team), ops.gls_prune_mode(prune):
         cfg = ops.gls_describe_config(n, B, c["bits"])
         assert cfg["team"] == (bool(team) and cfg["store"] != "global")          # n > ~200: the triangles leave the LDS
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],

@@ -120,7 +120,7 @@ def test_misc_golden(ops):
     assert_bits(c.cpu().numpy()[0], g["tc_cost"])
 
 
-VARIANTS = {"serial": 0, "team": 1}     # form of the perturbation phase
+VARIANTS = {"serial": (0, 1), "team": (1, 1), "fullscan": (0, 0)}     # (team form of the perturbation phase, pruned descent scans)
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
@@ -128,7 +128,9 @@ VARIANTS = {"serial": 0, "team": 1}     # form of the perturbation phase
 def test_gls_batch_vs_oracle(ops, n, B, K, variant):
     """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup; perturbation phase on wavefront 0
     (serial) and on all wavefronts of the workgroup (team)."""
-    team = VARIANTS[variant]
+    team, prune = VARIANTS[variant]
+    if not prune and n < 128:
+        pytest.skip("the pruned descent scans only exist for n >= 128: same kernel as the serial case")
     from oracle import gls_oracle as go
     rng = np.random.default_rng(1000 + n)
     D, _ = random_instances(rng, B, n)
@@ -139,7 +141,7 @@ def test_gls_batch_vs_oracle(ops, n, B, K, variant):
     d, gd = dev(D, torch.float64), dev(guides, torch.float64)
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
-    with ops.gls_team_mode(team):
+    with ops.gls_team_mode(team), ops.gls_prune_mode(prune):
         assert ops.gls_describe_config(n, B)["team"] == bool(team)
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=1 << 14, want_penalty=True)
     init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
@@ -160,8 +162,8 @@ def test_gls_batch_vs_oracle(ops, n, B, K, variant):
     (131, 3, 2, -2, "compact", 2), (131, 3, 2, 0, "lds-tri-i32", 1), (160, 3, 2, -2, "compact", 1),
     (160, 3, 2, 0, "lds-tri-i32", 1), (200, 3, 2, 0, "compact", 1), (200, 2, 1, -2, "compact", 1)])
 @pytest.mark.parametrize("fi", [False, True])
-@pytest.mark.parametrize("team", [0, -1], ids=["serial", "policy"])
-def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi, team):
+@pytest.mark.parametrize("team,prune", [(0, 1), (-1, 1), (0, 0)], ids=["serial", "policy", "fullscan"])
+def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi, team, prune):
     """BASELINE configs[4] regime (TSP200; n = 131..200): one or two workgroups per CU (up to 159 KB of LDS for the
     distance triangle), no row-on-the-lane descent (n - 1 > 128), four register passes of cached utilities -- on the
     store gnngls_gls_run picks by itself and on the compact store (the one TSP200 x 256 runs on).  Two guides, both
@@ -183,7 +185,7 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
     d, gd = dev(D, torch.float64), dev(guides, torch.float64)
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
-    with ops.gls_team_mode(team):
+    with ops.gls_team_mode(team), ops.gls_prune_mode(prune):
         assert ops.gls_describe_config(n, B, penalty_bits=bits)["team"] == (team != 0 and policy_team)
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
                         trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
