@@ -291,14 +291,13 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     void *nl = nullptr;          // nearest-neighbour lists of the pruned descent scans
     if (cfg.prune) {
         const size_t entries = (size_t)B * n * gnngls::kNeighborListLen;
-        e = hipMallocAsync(&nl, entries * sizeof(double) + (size_t)B * sizeof(int32_t) + entries, st);
+        e = hipMallocAsync(&nl, (size_t)B * sizeof(int32_t) + entries, st);
         if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour-list alloc"); }
-        double *nl_d = (double *)nl;
-        int32_t *ok = (int32_t *)(nl_d + entries);
+        int32_t *ok = (int32_t *)nl;
         uint8_t *nl_id = (uint8_t *)(ok + B);
-        e = gnngls::launch_neighbor_lists(D, B, n, nl_id, nl_d, ok, st);
+        e = gnngls::launch_neighbor_lists(D, B, n, nl_id, ok, st);
         if (e != hipSuccess) { (void)hipFreeAsync(nl, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour lists"); }
-        A.nl_id = nl_id; A.nl_d = nl_d; A.prune_ok = ok;
+        A.nl_id = nl_id; A.prune_ok = ok;
     }
     {
         ProfScope ps(GNNGLS_PROF_GLS, st);

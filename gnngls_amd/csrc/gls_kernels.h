@@ -38,8 +38,7 @@ struct GlsArgs {
     int32_t *imp_len;          // [B] number of improvements (may exceed imp_cap); written by the kernel
     // pruned descent scans (best improvement, symmetric stores, n >= 128): 32 nearest neighbours per node, see
     // neighbor_lists_kernel; NULL = full scans
-    const uint8_t *nl_id;      // [B,n,32]
-    const double *nl_d;        // [B,n,32]
+    const uint8_t *nl_id;      // [B,n,32] node ids, nearest first
     const int32_t *prune_ok;   // [B] 1 = the instance's matrix is within the magnitude bound of the pruning argument
 };
 
@@ -57,7 +56,7 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                       hipStream_t stream);
 constexpr int kNeighborListLen = 32;
 bool gls_prune_supported(int store, int n, bool first_improvement);
-hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok, hipStream_t stream);
+hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,
                             bool first_improvement, double *delta_out, int32_t *move_out, int32_t *new_tour,

@@ -889,9 +889,10 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
 //   relocate delta = ((base_i - D[d,e]) + D[d,b]) + D[b,e] with T = fl(D[d,e] - base_i): if 2 D[d,b] >= T and 2 D[b,e] >= T
 //           then fl(-T + D[d,b]) >= -T/2 and the last sum is >= 0 (rounding is monotone, T/2 is exact): a qualifying
 //           move has an endpoint y of its target edge with 2 D[b,y] < T, for ANY symmetric matrix (no triangle inequality).
-// Every node has a list of its kNL = 32 nearest nodes, ascending (id + distance, built once per instance by
-// neighbor_lists_kernel into global memory).  A thread owns ONE list entry of one tour row: 16 lanes per row (position
-// p, node x = t[p]), four rows per wavefront, the rows' distances arrive as one coalesced 128-byte read each.  Entries that
+// Every node has a list of its kNL = 32 nearest nodes, ascending (ids, one byte each, built once per instance by
+// neighbor_lists_kernel into global memory: 6.4 KB per TSP200 instance, L1-resident; the distances come from the LDS
+// triangle).  Eight lanes share a tour row (position p, node x = t[p]) and take two list entries each per level of 16,
+// eight rows per wavefront.  Entries that
 // pass the row's threshold look their node's position up and the few surviving candidates (~1000 / ~250 of 19,503 /
 // 39,204 moves per scan at n = 200) are evaluated with the reference's operand order -- same operands, same bits as the
 // full scans -- all at once under the exec mask.  A row whose 16th entry still passes takes entries 17..32 in a second
@@ -901,44 +902,51 @@ constexpr int kNL = 32;
 
 template <class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
-                                                        const uint8_t *nl_id, const double *nl_d, int n,
+                                                        const uint8_t *nl_id, int n,
                                                         int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
     const PlainDist<S> f{s};
-    const int tasks = 16 * (n - 1);
-    const int rowbit = (lane & 48) + 15;                     // lane that holds entry 15 / 31 of this lane's row
+    const int tasks = 8 * (n - 1);                           // 8 lanes per tour row, two list entries per lane and level
+    const int rowbit = (lane & 56) + 7;                      // lane that holds entries 15 / 31 of this lane's row
     for (int task0 = 0; task0 < tasks; task0 += nthr) {      // wave-uniform trip count; a wavefront's tasks are whole rows
         const int task = task0 + tid;
         const bool live = task < tasks;
-        const int p = 1 + (live ? task >> 4 : 0), m = task & 15;
+        const int p = 1 + (live ? task >> 3 : 0), m = task & 7;
         const int x = t[p], xm = t[p - 1], xp = t[p + 1];
         const double ep = Ef[p], es = Ef[p + 1];             // D[x, t[p-1]], D[x, t[p+1]]
         const double thr = ep > es ? ep : es;
         bool more = live;                                    // the row may hold candidates among its next 16 list entries
 #pragma unroll 1
         for (int lvl = 0; lvl < 2; ++lvl) {
-            const size_t e = (size_t)x * kNL + lvl * 16 + m;
-            const int y = nl_id[e];
-            const double d = nl_d[e];
-            const bool act = more && d < thr;
-            const int q = pos[y];
-            // y = t[q]: (a, c) = (x, y) of the move (i, j) = (p, q) if q >= p + 2; (d, b) = (x, y) of (q + 1, p + 1) if q <= p - 2
-            const bool ca = act && d < ep && q >= p + 2;
-            const bool cb = act && d < es && q <= p - 2 && p <= n - 2;
-            if (ca || cb) {
-                const int o2 = t[ca ? q - 1 : q + 1];
-                const double e2 = Ef[ca ? q : q + 1];
-                const double dpair = s.dist(ca ? xm : xp, o2);           // D[b,d] (A) / D[a,c] (B)
-                double delta = d + dpair;                                // operators.py:25-28 (the sum of two terms commutes)
-                delta = delta - (ca ? ep : e2);                          // - D[a,b]
-                delta = delta - (ca ? e2 : es);                          // - D[c,d]
-                consider<false>(delta, ca ? make_key(p, q) : make_key(q + 1, p + 1), bd, bk);
+            const uint8_t *ids = nl_id + (size_t)x * kNL + lvl * 16 + m;
+            const int y0 = ids[0], y1 = ids[8];              // entries m and m + 8 of this level
+            const double d0 = s.dist(x, y0), d1 = s.dist(x, y1);
+            const int q0 = pos[y0], q1 = pos[y1];
+            bool last = false;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double d = u ? d1 : d0;
+                const int q = u ? q1 : q0;
+                const bool act = more && d < thr;
+                // y = t[q]: (a, c) = (x, y) of the move (i, j) = (p, q) if q >= p + 2; (d, b) = (x, y) of (q + 1, p + 1) if q <= p - 2
+                const bool ca = act && d < ep && q >= p + 2;
+                const bool cb = act && d < es && q <= p - 2 && p <= n - 2;
+                if (ca || cb) {
+                    const int o2 = t[ca ? q - 1 : q + 1];
+                    const double e2 = Ef[ca ? q : q + 1];
+                    const double dpair = s.dist(ca ? xm : xp, o2);       // D[b,d] (A) / D[a,c] (B)
+                    double delta = d + dpair;                            // operators.py:25-28 (the sum of two terms commutes)
+                    delta = delta - (ca ? ep : e2);                      // - D[a,b]
+                    delta = delta - (ca ? e2 : es);                      // - D[c,d]
+                    consider<false>(delta, ca ? make_key(p, q) : make_key(q + 1, p + 1), bd, bk);
+                }
+                if (u == 1) last = act;
             }
-            const unsigned long long need = __ballot(act && m == 15);    // rows whose last entry of this level still passes
+            const unsigned long long need = __ballot(last && m == 7);    // rows whose last entry of this level still passes
             more = (need >> rowbit) & 1ull;
             if (!need) break;
         }
         // all 32 entries below the row's threshold: every move that has x as `a` (row p) or as `d` (column p + 1)
-        unsigned long long om = __ballot(more && m == 15);
+        unsigned long long om = __ballot(more && m == 7);
 #ifdef GLS_STAMPS
         if (dbg && lane == 0) { dbg[0] += __popcll(om); dbg[2] += 1; }
 #endif
@@ -955,16 +963,16 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
 
 template <class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
-                                                         const uint8_t *nl_id, const double *nl_d, int n, double Lcap,
+                                                         const uint8_t *nl_id, int n, double Lcap,
                                                          const int *longk, int nlong,
                                                          int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
     const PlainDist<S> f{s};
-    const int tasks = 16 * (n - 1);
-    const int rowbit = (lane & 48) + 15;
+    const int tasks = 8 * (n - 1);
+    const int rowbit = (lane & 56) + 7;
     for (int task0 = 0; task0 < tasks; task0 += nthr) {
         const int task = task0 + tid;
         const bool live = task < tasks;
-        const int p = 1 + (live ? task >> 4 : 0), m = task & 15;
+        const int p = 1 + (live ? task >> 3 : 0), m = task & 7;
         const int b = t[p];
         double base = -Ef[p];                                    // -D[a,b]          (operators.py:97-99, left to right)
         base = base - Ef[p + 1];                                 // -D[b,c]
@@ -974,47 +982,57 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
         // row evaluates them directly: a single long edge left by the perturbation phase would otherwise push every row's
         // threshold beyond its list (12.9 of 16 rows per wavefront overflowed with the tour's maximum edge as the bound).
         const double Tmax = Lcap - base;
-        if (live && m < nlong) {
-            const int k = longk[m];
-            if ((unsigned)(k - p + 2) > 2u) {
-                double delta = base - Ef[k + 1];                 // operators.py:100-102, left to right
-                delta = delta + s.dist(t[k], b);                 // +D[d,b]
-                delta = delta + s.dist(b, t[k + 1]);             // +D[b,e]
-                consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (live && m + 8 * u < nlong) {
+                const int k = longk[m + 8 * u];
+                if ((unsigned)(k - p + 2) > 2u) {
+                    double delta = base - Ef[k + 1];             // operators.py:100-102, left to right
+                    delta = delta + s.dist(t[k], b);             // +D[d,b]
+                    delta = delta + s.dist(b, t[k + 1]);         // +D[b,e]
+                    consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
+                }
             }
         }
         bool more = live;
 #pragma unroll 1
         for (int lvl = 0; lvl < 2; ++lvl) {
-            const size_t e = (size_t)b * kNL + lvl * 16 + m;
-            const int y = nl_id[e];
-            const double d = nl_d[e];
-            const double two_d = d + d;
-            const bool act = more && two_d < Tmax;
-            const int q = pos[y];
+            const uint8_t *ids = nl_id + (size_t)b * kNL + lvl * 16 + m;
+            const int y0 = ids[0], y1 = ids[8];
+            const double d0 = s.dist(b, y0), d1 = s.dist(b, y1);
+            const int q0 = pos[y0], q1 = pos[y1];
             // y = t[q] is d of target edge k1 = q and e of target edge k2 = q - 1 (the depot closes the tour: e = t[n])
-            const int k1 = q, k2 = y == 0 ? n - 1 : q - 1;
-            const double e1 = Ef[k1 + 1], e2 = Ef[k2 + 1];       // D[d,e]
-            // valid targets of row p: k not in {p-2, p-1, p} (operators.py:133-136: i - j == 1 <=> k = p - 2)
-            const bool c1 = act && (unsigned)(k1 - p + 2) > 2u && two_d < e1 - base;
-            const bool c2 = act && (unsigned)(k2 - p + 2) > 2u && two_d < e2 - base;
-            if (c1) {
-                double delta = base - e1;                        // operators.py:100-102, left to right
-                delta = delta + d;                               // +D[d,b]
-                delta = delta + s.dist(b, t[k1 + 1]);            // +D[b,e]
-                consider<false>(delta, make_key(p, k1 < p ? k1 + 1 : k1), bd, bk);
+            const int k20 = y0 == 0 ? n - 1 : q0 - 1, k21 = y1 == 0 ? n - 1 : q1 - 1;
+            const double e10 = Ef[q0 + 1], e20 = Ef[k20 + 1], e11 = Ef[q1 + 1], e21 = Ef[k21 + 1];     // D[d,e]
+            bool last = false;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double d = u ? d1 : d0, e1 = u ? e11 : e10, e2 = u ? e21 : e20;
+                const int k1 = u ? q1 : q0, k2 = u ? k21 : k20;
+                const double two_d = d + d;
+                const bool act = more && two_d < Tmax;
+                // valid targets of row p: k not in {p-2, p-1, p} (operators.py:133-136: i - j == 1 <=> k = p - 2)
+                const bool c1 = act && (unsigned)(k1 - p + 2) > 2u && two_d < e1 - base;
+                const bool c2 = act && (unsigned)(k2 - p + 2) > 2u && two_d < e2 - base;
+                if (c1) {
+                    double delta = base - e1;                    // operators.py:100-102, left to right
+                    delta = delta + d;                           // +D[d,b]
+                    delta = delta + s.dist(b, t[k1 + 1]);        // +D[b,e]
+                    consider<false>(delta, make_key(p, k1 < p ? k1 + 1 : k1), bd, bk);
+                }
+                if (c2) {
+                    double delta = base - e2;
+                    delta = delta + s.dist(t[k2], b);            // +D[d,b]
+                    delta = delta + d;                           // +D[b,e]
+                    consider<false>(delta, make_key(p, k2 < p ? k2 + 1 : k2), bd, bk);
+                }
+                if (u == 1) last = act;
             }
-            if (c2) {
-                double delta = base - e2;
-                delta = delta + s.dist(t[k2], b);                // +D[d,b]
-                delta = delta + d;                               // +D[b,e]
-                consider<false>(delta, make_key(p, k2 < p ? k2 + 1 : k2), bd, bk);
-            }
-            const unsigned long long need = __ballot(act && m == 15);
+            const unsigned long long need = __ballot(last && m == 7);
             more = (need >> rowbit) & 1ull;
             if (!need) break;
         }
-        unsigned long long om = __ballot(more && m == 15);
+        unsigned long long om = __ballot(more && m == 7);
 #ifdef GLS_STAMPS
         if (dbg && lane == 0) { dbg[1] += __popcll(om); dbg[3] += 1; }
 #endif
@@ -1047,7 +1065,7 @@ __device__ __forceinline__ void lmax_raise(Ctl *ctl, double v) {
 
 // Nearest-neighbour lists of the pruned scans: one workgroup per instance, thread x selects the kNL nearest nodes of x by
 // (D[x,y], y) ascending.  prune_ok[b] = every entry finite and |D| <= 1e6 (see above).
-__global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok) {
+__global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, int32_t *prune_ok) {
     const int b = blockIdx.x;
     const double *Dg = D + (size_t)b * n * n;
     int bad = 0;
@@ -1062,9 +1080,7 @@ __global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, do
                 if (m == 0 && !(fabs(v) <= 1e6)) bad = 1;        // also catches NaN / inf
                 if ((v > last_d || (v == last_d && y > last_y)) && (by < 0 || v < best)) { best = v; by = y; }
             }
-            const size_t o = ((size_t)b * n + x) * kNL + m;
-            nl_id[o] = (uint8_t)(by < 0 ? 0 : by);
-            nl_d[o] = best;
+            nl_id[((size_t)b * n + x) * kNL + m] = (uint8_t)(by < 0 ? (x == 0 ? 1 : 0) : by);      // (never x itself)
             last_d = best; last_y = by;
         }
     }
@@ -1453,7 +1469,7 @@ struct Trace<false> {
 
 // neighbour lists of the pruned descent scans for this instance (on = false: the full scans run); ppos = node -> position
 struct PruneCtx {
-    const uint8_t *id; const double *d; bool on;
+    const uint8_t *id; bool on;
 };
 
 template <class S, bool FI, int GP, class TT, class TRC>
@@ -1528,8 +1544,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 #else
                     long long *dbg = nullptr;
 #endif
-                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, pc.d, n, tid, nthr, lane, bd, bk, dbg);
-                    else         scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, pc.d, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
+                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, tid, nthr, lane, bd, bk, dbg);
+                    else         scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
                     lean = true;
                 }
             }
@@ -1667,8 +1683,8 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
     if (!FI && nthr > kWave) { block_reduce_lds_init(ctl, tid); __syncthreads(); }
     STAMP_BEGIN();
-    PruneCtx pc{nullptr, nullptr, false};
-    if (A.nl_id && A.prune_ok[b]) { pc.id = A.nl_id + (size_t)b * n * kNL; pc.d = A.nl_d + (size_t)b * n * kNL; pc.on = true; }
+    PruneCtx pc{nullptr, false};
+    if (A.nl_id && A.prune_ok[b]) { pc.id = A.nl_id + (size_t)b * n * kNL; pc.on = true; }
     local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
@@ -2103,9 +2119,9 @@ bool gls_prune_supported(int store, int n, bool first_improvement) {
     return store != GLS_STORE_GLOBAL && !first_improvement && n + 1 > 2 * kWave && n <= 255;
 }
 
-hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, double *nl_d, int32_t *prune_ok, hipStream_t stream) {
+hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(neighbor_lists_kernel, dim3(B), dim3(256), 0, stream, D, n, nl_id, nl_d, prune_ok);
+    hipLaunchKernelGGL(neighbor_lists_kernel, dim3(B), dim3(256), 0, stream, D, n, nl_id, prune_ok);
     return hipGetLastError();
 }
 
