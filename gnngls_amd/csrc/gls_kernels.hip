@@ -46,6 +46,9 @@ namespace gnngls {
 #ifndef GLS_PERTURB_PRIO
 #define GLS_PERTURB_PRIO 3           // s_setprio of the wavefront that carries the perturbation phase
 #endif
+#ifndef GLS_LCAP_FACTOR
+#define GLS_LCAP_FACTOR 3.0          // pruned relocate scan: tour edges longer than this many mean edge lengths are listed per scan
+#endif
 #ifndef GLS_PRUNE_TWO_OPT_ONLY
 #define GLS_PRUNE_TWO_OPT_ONLY 0     // experiments: 1 = only the 2-opt descent scan is pruned
 #endif
@@ -1513,7 +1516,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     // pruned relocate scan: tour edges longer than Lcap (three mean edge lengths of the tour the descent starts from) are
     // listed per scan (at most kLongCap, else that scan runs unpruned) in exchange slots the descent does not use
     constexpr int kLongCap = 16;
-    const double Lcap = 3.0 * cur_cost / (double)n;
+    const double Lcap = GLS_LCAP_FACTOR * cur_cost / (double)n;
     int *longk = reinterpret_cast<int *>(&ctl->red_d[0][3]);     // 16 ints: bytes 24 .. 87 of red_d
     int *nlong_slot = &ctl->red_k[1][0];
     (void)Lmax;
