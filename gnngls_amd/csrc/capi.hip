@@ -98,15 +98,11 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
     return c;
 }
 
-// + the pruned descent scans (nearest-neighbour lists; 4-slot instantiations, n >= 128) where the position table still fits
+// + the pruned descent scans (nearest-neighbour lists: 2-opt scan from n = 80, relocate scan from n = 128; the position table
+// sits in the LDS slot the best tour used to have, so the footprint does not change)
 GlsConfig gls_config_run(int n, int requested_bits, int batch, bool first_improvement) {
     GlsConfig c = gls_config(n, requested_bits, batch);
-    if (g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement) &&
-        (c.wps == 4 || c.store == gnngls::GLS_STORE_TRI)) {
-        const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, c.team, true);
-        const int per_cu = (int)(kLdsPerCU / (lds ? lds : 1));
-        if (lds <= kLdsPerCU && per_cu >= c.per_cu) { c.prune = true; c.lds = lds; }      // never at the price of residency
-    }
+    c.prune = g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement);
     return c;
 }
 

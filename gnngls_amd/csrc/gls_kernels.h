@@ -36,14 +36,14 @@ struct GlsArgs {
     long long *imp_iter;       // [B,imp_cap] completed outer iterations at that moment, or NULL
     int imp_cap;
     int32_t *imp_len;          // [B] number of improvements (may exceed imp_cap); written by the kernel
-    // pruned descent scans (best improvement, symmetric stores, n >= 128): 32 nearest neighbours per node, see
+    // pruned descent scans (best improvement, symmetric stores, n >= 80): 32 nearest neighbours per node, see
     // neighbor_lists_kernel; NULL = full scans
     const uint8_t *nl_id;      // [B,n,32] node ids, nearest first
     const int32_t *prune_ok;   // [B] 1 = the instance's matrix is within the magnitude bound of the pruning argument
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
-size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false, bool prune = false);
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false);
 int gls_block_threads(int n, int store);
 void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 // resident wavefronts per SIMD (= register budget) of the kernel instantiation for this configuration: 4 or 8 for the

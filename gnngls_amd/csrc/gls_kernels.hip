@@ -49,9 +49,6 @@ namespace gnngls {
 #ifndef GLS_LCAP_FACTOR
 #define GLS_LCAP_FACTOR 3.0          // pruned relocate scan: tour edges longer than this many mean edge lengths are listed per scan
 #endif
-#ifndef GLS_PRUNE_TWO_OPT_ONLY
-#define GLS_PRUNE_TWO_OPT_ONLY 0     // experiments: 1 = only the 2-opt descent scan is pruned
-#endif
 #ifndef GLS_TEAM_SCANS
 #define GLS_TEAM_SCANS 4             // team form: one-to-all scans evaluated per round (4 = both endpoints, 2 = one endpoint, 1)
 #endif
@@ -881,7 +878,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     }
 }
 
-// ---- pruned a2a scans (best improvement, symmetric stores, n >= 130: the 4-slot instantiations) -----------------------
+// ---- pruned a2a scans (best improvement, symmetric stores; 2-opt from n = 80, relocate from n = 128) -------------------
 // The descent needs, per scan, the lexicographic minimum of (delta, i, j) over the moves that qualify (delta < 0 and not
 // np.isclose(0, delta), operators.py:42).  Any SUPERSET of the qualifying moves gives the same minimum, and most of the
 // O(n^2) moves of a tour that is a few moves away from a local optimum cannot qualify:
@@ -902,6 +899,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
 // step; a row whose 32nd entry passes is evaluated in full by its wavefront (rare).  Tour-edge lengths are bounded by
 // Lmax (an upper bound of Ef[], kept by local_search_dev).
 constexpr int kNL = 32;
+constexpr int kPruneMinNodes = 80;       // 2-opt scan pruned from here up (same-box A/B at n = 66 .. 127), relocate from n = 128
 
 template <class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
@@ -1481,7 +1479,10 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                                  TT *ppos, const PruneCtx &pc) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
-    constexpr bool kCanPrune = !FI && S::kSymmetric && GP == 4;      // compiled into the 4-slot instantiations (n >= 128) only
+    // pruned descent scans (given neighbour lists): the 2-opt scan from n = 80 up, the relocate scan from n = 128 up (the
+    // 4-slot instantiations) -- where each was measured faster (profiles/r03_experiments/README.md)
+    constexpr bool kCanPrune = !FI && S::kSymmetric;
+    constexpr bool kPruneRelocate = kCanPrune && GP == 4;
     const bool prune = kCanPrune && pc.on;
     double Lmax = 0.0;
     if (prune) {
@@ -1529,7 +1530,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             bool lean = false;
             if constexpr (kCanPrune) {
                 int nlong = 0;
-                if (prune && op == 1 && !GLS_PRUNE_TWO_OPT_ONLY) {
+                if (kPruneRelocate && prune && op == 1) {
                     if (tid == 0) *nlong_slot = 0;
                     __syncthreads();
                     for (int q = 1 + tid; q <= n; q += nthr)
@@ -1541,14 +1542,18 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                     __syncthreads();
                     nlong = *nlong_slot;
                 }
-                if (prune && (op == 0 || (!GLS_PRUNE_TWO_OPT_ONLY && nlong <= kLongCap))) {
+#ifdef GLS_STAMPS
+                if (prune && op == 1 && nlong > kLongCap) st.acc[15] += 1;      // relocate scans that fell back to the full scan
+#endif
+                if (prune && (op == 0 || (kPruneRelocate && nlong <= kLongCap))) {
 #ifdef GLS_STAMPS
                     long long *dbg = &st.acc[16];            // overflow rows (2-opt, relocate), wave-passes (2-opt, relocate)
 #else
                     long long *dbg = nullptr;
 #endif
                     if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, tid, nthr, lane, bd, bk, dbg);
-                    else         scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
+                    else if constexpr (kPruneRelocate)
+                        scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
                     lean = true;
                 }
             }
@@ -1619,9 +1624,11 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     using TT = typename S::tour_t;
     TT *t = reinterpret_cast<TT *>(smem + off);                off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
     TT *t2 = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
-    TT *bt = reinterpret_cast<TT *>(smem + off);               off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
-    TT *ppos = nullptr;                                        // node -> position table of the pruned descent scans
-    if (A.nl_id) { ppos = reinterpret_cast<TT *>(smem + off);  off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15); }
+    // the best tour lives in the output array (written whenever the best improves: a few dozen times per run); its former
+    // LDS slot holds the node -> position table of the pruned descent scans, so those cost no LDS (the compact store's
+    // 40 KiB at n = 100 have no spare byte)
+    int32_t *bt = A.best_tour + (size_t)b * (n + 1);
+    TT *ppos = reinterpret_cast<TT *>(smem + off);             off += ((size_t)(n + 1) * sizeof(TT) + 15) & ~size_t(15);
 
     S s;
     if constexpr (S::kSymmetric) {
@@ -1647,7 +1654,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     } else {
         s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host
     }
-    for (int p = tid; p <= n; p += nthr) { int v = A.init_tour[(size_t)b * (n + 1) + p]; t[p] = (TT)v; bt[p] = (TT)v; }
+    for (int p = tid; p <= n; p += nthr) { int v = A.init_tour[(size_t)b * (n + 1) + p]; t[p] = (TT)v; }
     __syncthreads();
 
     const long long t_start = wall_clock64();
@@ -1691,7 +1698,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
-    for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
+    for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
     __syncthreads();
 
     long long iter_i = 0;
@@ -1847,7 +1854,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
-            for (int p = tid; p <= n; p += nthr) bt[p] = t[p];
+            for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
             if (tid == 0) push_improvement(best_cost, iter_i + 1);
         }
         iter_i++;
@@ -1855,7 +1862,6 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     }
 
     // ---- outputs ----
-    for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = (int32_t)bt[p];
     if (tid == 0 && A.imp_len) {
         // terminal entry (returned best, end of the search, completed iterations): always the last one, always counted
         // (imp_len = improvements + 1 also when imp_cap == 0, as the header says) and, given a buffer, always stored --
@@ -1885,7 +1891,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         // descent's scan cycles and its arg-min + wait cycles
         long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
         if (TEAM) o2[wave] = st.acc[12];
-        else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; }   // pruned-scan counters
+        else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; o2[4] = st.acc[15]; }   // pruned-scan counters
         o2[(size_t)A.B * 16 + wave] = st.acc[8];
         o2[(size_t)A.B * 32 + wave] = st.acc[9];
     }
@@ -2006,12 +2012,11 @@ __global__ void nearest_neighbor_kernel(const double *W, int n, int depot, int32
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------------------
-size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team, bool prune) {
+size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team) {
     auto r16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t tour_elem = store == GLS_STORE_COMPACT ? 1 : 4;
     size_t off = r16(sizeof(Ctl)) + r16((size_t)(n + 2) * 8) + 3 * r16((size_t)(n + 1) * tour_elem);
     if (team) off += r16(sizeof(TeamCtl));
-    if (prune) off += r16((size_t)(n + 1) * tour_elem);                 // node -> position table
     if (store == GLS_STORE_GLOBAL) off += r16((size_t)(n + 2) * 8);
     size_t ntri = (size_t)n * (n - 1) / 2;
     if (store != GLS_STORE_GLOBAL) off += r16(ntri * 8);
@@ -2100,7 +2105,7 @@ bool gls_team_supported(int store, int penalty_bits, int wps, int n) {
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream) {
     if (team && !gls_team_supported(store, penalty_bits, wps, A.n)) return hipErrorInvalidValue;
-    size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team, A.nl_id != nullptr);
+    size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
     if (store == GLS_STORE_COMPACT) {
         if (team) return launch_gls_f<TriDGlobalPF, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)
@@ -2119,7 +2124,7 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
 // pruned descent scans exist in the 4-slot instantiations of the symmetric stores (n >= 128), best improvement only; the
 // lists must be full (n - 1 >= 32)
 bool gls_prune_supported(int store, int n, bool first_improvement) {
-    return store != GLS_STORE_GLOBAL && !first_improvement && n + 1 > 2 * kWave && n <= 255;
+    return store != GLS_STORE_GLOBAL && !first_improvement && n >= kPruneMinNodes && n <= 255;
 }
 
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream) {

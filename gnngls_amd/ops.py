@@ -201,7 +201,7 @@ class gls_team_mode:
 
 class gls_prune_mode:
     """Experiment / test hook (gnngls_debug_set_gls_prune): `with gls_prune_mode(0): ...` makes the descent evaluate every
-    move of its all-to-all scans instead of the pruned candidate sets (n >= 128).  Results are bit-identical either way."""
+    move of its all-to-all scans instead of the pruned candidate sets (n >= 80).  Results are bit-identical either way."""
 
     def __init__(self, mode):
         self.mode = int(mode)

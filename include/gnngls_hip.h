@@ -212,7 +212,8 @@ int gnngls_gls_uses_team(int n, int B, int penalty_bits);
 int gnngls_debug_set_gls_team(int mode);
 
 /* Experiment / test hook: 0 = the descent (algorithms.py:111-132) evaluates every move of an all-to-all scan; -1 / 1
- * (default) = the pruned scans where they exist (best improvement, symmetric LDS stores, n >= 128, max |D| <= 1e6): per
+ * (default) = the pruned scans where they exist (best improvement, symmetric LDS stores, max |D| <= 1e6; the 2-opt scan from
+ * n = 80, the relocate scan from n = 128): per
  * node a list of its 32 nearest nodes, only moves that can qualify are evaluated -- a superset of the qualifying moves,
  * hence the same arg-min, bit-exact.  Never called by the product. */
 int gnngls_debug_set_gls_prune(int mode);

@@ -50,10 +50,10 @@ VARIANTS = {"serial": (0, 1), "team": (1, 1), "fullscan": (0, 0)}     # (team fo
 def test_fuzz_case(c, variant):
     """Kernel variants, all bit-exact: `serial` = perturbation phase on wavefront 0 (what a device-filling batch runs);
     `team` = on all wavefronts of the workgroup wherever that form exists; both with the pruned descent scans where those
-    exist (n >= 128, the default); `fullscan` = the descent evaluates every move of its scans."""
+    exist (n >= 80, the default); `fullscan` = the descent evaluates every move of its scans."""
     team, prune = VARIANTS[variant]
-    if not prune and c["n"] < 128:
-        pytest.skip("the pruned descent scans only exist for n >= 128: same kernel as the serial case")
+    if not prune and c["n"] < 80:
+        pytest.skip("the pruned descent scans only exist for n >= 80: same kernel as the serial case")
     from gnngls_amd import ops
     from oracle import gls_oracle as go
     if team and c["bits"] == 16:

@@ -129,8 +129,8 @@ def test_gls_batch_vs_oracle(ops, n, B, K, variant):
     """Seeded random batches: HIP path vs the CPU oracle, one instance per workgroup; perturbation phase on wavefront 0
     (serial) and on all wavefronts of the workgroup (team)."""
     team, prune = VARIANTS[variant]
-    if not prune and n < 128:
-        pytest.skip("the pruned descent scans only exist for n >= 128: same kernel as the serial case")
+    if not prune and n < 80:
+        pytest.skip("the pruned descent scans only exist for n >= 80: same kernel as the serial case")
     from oracle import gls_oracle as go
     rng = np.random.default_rng(1000 + n)
     D, _ = random_instances(rng, B, n)
