@@ -245,7 +245,10 @@ def main():
     # backend "nccl" is RCCL on ROCm; GNNGLS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box
     # with fewer GPUs than ranks (the gather then goes through host memory)
     backend = os.environ.get("GNNGLS_DIST_BACKEND", "nccl")
-    if world > 1:
+    # GNNGLS_DIST_SINGLE=1: form the process group also for ONE rank, so that a one-GPU box runs every collective of the
+    # N-rank path on RCCL (tests/test_bench_gpu.py); the driver's N=1 run does not set it and touches no collective
+    grouped = world > 1 or os.environ.get("GNNGLS_DIST_SINGLE", "0") == "1"
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         else:
@@ -269,7 +272,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -281,7 +284,7 @@ def main():
                                  perturbation_moves=args.perturbation_moves, chunk=chunk_eff, budget=args.budget)
         local = torch.stack([r.best_cost, r.init_cost, r.outer_iters.double(), r.evals.double(),
                              r.status.double()], dim=1).contiguous()           # [B, 5] fp64
-        if world > 1 and backend != "nccl":
+        if grouped and backend != "nccl":
             g = parallel.gather_results(local.cpu(), sizes)
             gathered = g.cuda() if g is not None else None
         else:
@@ -307,7 +310,7 @@ def main():
     gls_ms, gls_launches = prof["gls"]
     mine = torch.tensor([gls_ms, float(gls_launches), float(rounds)], dtype=torch.float64, device=stats_dev)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_gather(per_rank, mine)                                        # outside the timed region: reporting only
     else:
@@ -420,7 +423,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(D_host[:cores], guides_host, init.cpu().numpy(), init_cost.cpu().numpy(),
                                                bk, args.time_limit, args.perturbation_moves, cores)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -22,7 +22,7 @@ def gather_results(local, sizes=None, dst=0):
     """local [B_local, C] tensor on every rank -> concatenated [sum B_local, C] on rank `dst`, None elsewhere: ONE
     collective (`gather`).  `sizes` = rows per rank (shard_sizes(total, world)) when the shards are uneven; None means
     every rank holds the same number of rows.  No size exchange: the shard layout is a function of (total, world)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     if sizes is None:

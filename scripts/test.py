@@ -67,7 +67,7 @@ def parse_args():
 def init_ranks():
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
-    if world > 1:
+    if world > 1 or os.environ.get('GNNGLS_DIST_SINGLE', '0') == '1':       # the latter: one rank through RCCL (GPU tests)
         dist.init_process_group(os.environ.get('GNNGLS_DIST_BACKEND', 'nccl'))
     return world, rank
 
@@ -151,7 +151,7 @@ def solve_block(names, test_set, model, scalers, args, chunk, budget='per_instan
 
 
 def gather_records(records, world, rank):
-    if world == 1:
+    if not dist.is_initialized():
         return records
     parts = [None] * world if rank == 0 else None
     dist.gather_object(records, parts, dst=0)                                 # the one exchange of the run

@@ -33,6 +33,20 @@ def test_bench_single_rank_small():
     assert "bench_data/" in j["gap_reference"] and j["mean_gap_pct"] >= 0 and j["instances_below_reference"] == 0
 
 
+def test_bench_one_rank_through_rccl():
+    """backend "nccl" (= RCCL) with a process group of ONE rank: the torchrun launch of the driver, device-side gather,
+    barrier, all_reduce(MAX) and all_gather of the N-rank path all execute on RCCL -- what a one-GPU box can run of it."""
+    env = dict(os.environ, GNNGLS_DIST_SINGLE="1")
+    env.pop("GNNGLS_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--batch", "64", "--time_limit", "0.5", "--no_cpu_baseline"]
+    out = subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.STDOUT, timeout=600)
+    j = last_json_line(out)
+    assert j["n_gpus"] == 1 and 64 / 1.5 < j["value"] < 64 / 0.45 and j["watchdog_aborts"] == 0
+    assert j["config"]["rounds_per_rank"] == [1] and len(j["gls_ms_per_rank"]) == 1 and j["mean_gap_pct"] >= 0
+
+
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, GNNGLS_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

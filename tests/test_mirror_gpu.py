@@ -152,6 +152,17 @@ def test_cli_end_to_end(tmp_path):
             "127.0.0.1", "--master-port", "29544"] + cmd[1:]
     cmd2[cmd2.index(str(run_dir))] = str(run_dir2)
     subprocess.check_call(cmd2, cwd=ROOT, env=dict(os.environ, GNNGLS_DIST_BACKEND="gloo"))
+    # ... and as ONE rank whose process group is RCCL (backend "nccl"): the exchange of the N-GPU launch, on one GPU
+    run_dir3 = tmp_path / "runs3"
+    cmd3 = [c.replace("--nproc-per-node=2", "") for c in cmd2]
+    cmd3[cmd3.index("--nproc-per-node") + 1] = "1"
+    cmd3[cmd3.index("--master-port") + 1] = "29545"
+    cmd3[cmd3.index(str(run_dir2))] = str(run_dir3)
+    env3 = dict(os.environ, GNNGLS_DIST_SINGLE="1")
+    env3.pop("GNNGLS_DIST_BACKEND", None)
+    subprocess.check_call(cmd3, cwd=ROOT, env=env3)
+    df3 = pickle.load(open(list(run_dir3.glob("*.pkl"))[0], "rb"))
+    assert sorted(df3["instance"].unique()) == names
     out2 = list(run_dir2.glob("*.pkl"))
     assert len(out2) == 1
     df2 = pickle.load(open(out2[0], "rb"))
