@@ -1307,10 +1307,18 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
     const int NQ = (n + kWave - 1) / kWave;                  // blocks of 64 tour positions 0 .. n-1
     double gq = 0.0; int pq = 0;                             // utility numerator and penalty of tour edge (p, p+1), p = 64 wave + lane
     const int myp = wave * kWave + lane;
-    auto reload = [&]() {                                    // asynchronous: consumed by the next arg-max
-        if (wave < NQ && myp < n) { const int u = t[myp], v = t[myp + 1]; gq = guide[(size_t)u * n + v]; pq = s.pen(u, v); }
+    // (qk, qk2, pk): the counter this step incremented (packed index / both matrix cells, new count) -- substituted for
+    // whatever the load returns, as in the scans: another wavefront's store of it may still be in flight
+    auto reload = [&](int qk, int qk2, int pk) {             // asynchronous: consumed by the next arg-max
+        if (wave < NQ && myp < n) {
+            const int u = t[myp], v = t[myp + 1];
+            gq = guide[(size_t)u * n + v];
+            const int q = PenRowMajor<S>::value ? u * n + v : s.idx(u, v);
+            pq = s.pen(u, v);
+            if (q == qk || (PenRowMajor<S>::value && q == qk2)) pq = pk;
+        }
     };
-    reload();
+    reload(-1, -1, 0);
     if (tid == 0) tc->stop = 0;
     int moves = 0;
     long long steps = 0;
@@ -1420,6 +1428,11 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
             { TT *x = t; t = t2; t2 = x; }
             lds_barrier();
             any_moved = true; moved_this_step = true;
+            // the cached utilities are only read by the next arg-max: reloaded after EVERY move, so that the guide-matrix
+            // loads (HBM / MALL latency) of all but a step's last move fly under its remaining rounds.  The positions belong to
+            // wavefronts 0 .. NQ-1, whose units (scan 0: two_opt_o2a of the first endpoint) only run in a step's first round:
+            // their vector-memory queue (loads return in order) is idle until the next step
+            reload(q_inc, q_inc2, p_inc);
             moves += 1;                                      // algorithms.py:185
             if (eager_cost) {
                 cur_cost = tour_cost_from_edges(Ef, n);      // algorithms.py:176 (every thread: the value stays uniform)
@@ -1431,10 +1444,6 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
             s_begin = found + 1;
             if (s_begin >= 4) break;
         }
-        // the cached utilities are only read by the next arg-max: ONE reload per step, issued after its last round -- a
-        // reload after every move put its guide-matrix loads (HBM / MALL latency) in front of the next round's penalty
-        // loads of the same wavefront (vector memory returns in order)
-        if (moved_this_step) reload();
         steps++;
         STAMP_COUNT(6);
     }
