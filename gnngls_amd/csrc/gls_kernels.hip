@@ -1225,6 +1225,9 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k,
     const int r2 = a * n + b, r3 = c * n + d;                // the two tour edges (one of them wave-uniform)
     int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2], p3 = s.p[r3];
     const double d0 = s.dist(a, c), d1 = s.dist(b, d), d2 = s.dist(a, b), d3 = s.dist(c, d);
+    // all counter loads in flight before the first one is consumed: left alone, the compiler sinks each load to its
+    // substitution below and waits for it there -- four (relocate: three) memory round trips in a row per unit
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
     p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1;
     p2 = (r2 == qk1 || r2 == qk2) ? pk : p2; p3 = (r3 == qk1 || r3 == qk2) ? pk : p3;
     const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
@@ -1249,6 +1252,7 @@ __device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k
     int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2];
     const double dab = s.dist(a, b), dbc = s.dist(b, c), dac = s.dist(a, c);
     const double d0 = s.dist(d, e), d1 = s.dist(d, b), d2 = s.dist(b, e);
+    asm volatile("" : "+v"(pab), "+v"(pbc), "+v"(pac), "+v"(p0), "+v"(p1), "+v"(p2));      // see scan_two_opt_o2a_guided_rm
     pab = (rab == qk1 || rab == qk2) ? pk : pab; pbc = (rbc == qk1 || rbc == qk2) ? pk : pbc; pac = (rac == qk1 || rac == qk2) ? pk : pac;
     p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1; p2 = (r2 == qk1 || r2 == qk2) ? pk : p2;
     const double gab = dab + k * (double)pab, gbc = dbc + k * (double)pbc, gac = dac + k * (double)pac;
