@@ -182,6 +182,11 @@ struct TriDGlobalP {
 struct TriDGlobalPF : TriDGlobalP {
     int n;
     __device__ __forceinline__ int pen(int a, int b) const { return p[a * n + b]; }
+    // matrix cell r = row * n + column >= 0: base (scalar registers) + an unsigned 32-bit byte offset -- the load takes the
+    // offset register as it is; an int index costs a sign extension and a 64-bit add per load
+    __device__ __forceinline__ int cell(int r) const {
+        return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(p) + ((unsigned)r << 2));
+    }
     __device__ __forceinline__ bool pen_inc(int a, int b) const { p[a * n + b] += 1; p[b * n + a] += 1; return false; }
     __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {
         p[a * n + b] = old_count + 1; p[b * n + a] = old_count + 1;
@@ -1218,23 +1223,24 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k,
     int dj = i - j; if (dj < 0) dj = -dj;
     if (j > n - 1 || dj < 2) return;                         // operators.py:61-62
     const bool lt = i < j;
-    const int ii = lt ? i : j, jj = lt ? j : i;              // operators.py:17-18
-    const int a = t[ii], b = t[ii - 1], c = t[jj], d = t[jj - 1];
-    const int r0 = lt ? a * n + c : c * n + a;               // {a,c}: row of t[i]
-    const int r1 = lt ? b * n + d : d * n + b;               // {b,d}: row of t[i-1]
-    const int r2 = a * n + b, r3 = c * n + d;                // the two tour edges (one of them wave-uniform)
-    int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2], p3 = s.p[r3];
-    const double d0 = s.dist(a, c), d1 = s.dist(b, d), d2 = s.dist(a, b), d3 = s.dist(c, d);
+    // {a,c} = {t[i],t[j]} and {b,d} = {t[i-1],t[j-1]} whichever of i, j is smaller; the removed edges are the scan's own
+    // (t[i-1],t[i]) and the lane's (t[j-1],t[j]), only their order in the sum depends on i < j (operators.py:17-18,25-28)
+    const int ti = t[i], tim = t[i - 1], tj = t[j], tjm = t[j - 1];
+    const int r0 = ti * n + tj;                              // row of t[i]
+    const int r1 = tim * n + tjm;                            // row of t[i-1]
+    const int ru = ti * n + tim, rl = tj * n + tjm;          // the two tour edges (ru wave-uniform)
+    int p0 = s.cell(r0), p1 = s.cell(r1), pu = s.cell(ru), pl = s.cell(rl);
+    const double d0 = s.dist(ti, tj), d1 = s.dist(tim, tjm), du = s.dist(ti, tim), dl = s.dist(tj, tjm);
     // all counter loads in flight before the first one is consumed: left alone, the compiler sinks each load to its
     // substitution below and waits for it there -- four (relocate: three) memory round trips in a row per unit
-    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(pu), "+v"(pl));
     p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1;
-    p2 = (r2 == qk1 || r2 == qk2) ? pk : p2; p3 = (r3 == qk1 || r3 == qk2) ? pk : p3;
+    pu = (ru == qk1 || ru == qk2) ? pk : pu; pl = (rl == qk1 || rl == qk2) ? pk : pl;
     const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
-    const double g2 = d2 + k * (double)p2, g3 = d3 + k * (double)p3;
+    const double gu = du + k * (double)pu, gl = dl + k * (double)pl;
     double delta = g0 + g1;                                  // operators.py:25-28, left to right
-    delta = delta - g2;
-    delta = delta - g3;
+    delta = delta - (lt ? gu : gl);                          // - G[a,b]
+    delta = delta - (lt ? gl : gu);                          // - G[c,d]
     consider<FI>(delta, j, bd, bk);
 }
 
@@ -1243,13 +1249,13 @@ __device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k
                                                             int qk1, int qk2, int pk, double &bd, int &bk) {
     const int a = t[i - 1], b = t[i], c = t[i + 1];
     const int rab = b * n + a, rbc = b * n + c, rac = a * n + c;
-    int pab = s.p[rab], pbc = s.p[rbc], pac = s.p[rac];
+    int pab = s.cell(rab), pbc = s.cell(rbc), pac = s.cell(rac);
     const bool live = j <= n - 1 && j != i;                  // operators.py:114-115
     const int jc = live ? j : (i == 1 ? 2 : 1);
     int d, e;
     if (i < jc) { d = t[jc]; e = t[jc + 1]; } else { d = t[jc - 1]; e = t[jc]; }
     const int r0 = d * n + e, r1 = b * n + d, r2 = b * n + e;        // {d,e}: the lane's tour edge; {d,b}, {b,e}: row of b
-    int p0 = s.p[r0], p1 = s.p[r1], p2 = s.p[r2];
+    int p0 = s.cell(r0), p1 = s.cell(r1), p2 = s.cell(r2);
     const double dab = s.dist(a, b), dbc = s.dist(b, c), dac = s.dist(a, c);
     const double d0 = s.dist(d, e), d1 = s.dist(d, b), d2 = s.dist(b, e);
     asm volatile("" : "+v"(pab), "+v"(pbc), "+v"(pac), "+v"(p0), "+v"(p1), "+v"(p2));      // see scan_two_opt_o2a_guided_rm
