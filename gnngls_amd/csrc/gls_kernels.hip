@@ -904,27 +904,41 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
 // step; a row whose 32nd entry passes is evaluated in full by its wavefront (rare).  Tour-edge lengths are bounded by
 // Lmax (an upper bound of Ef[], kept by local_search_dev).
 constexpr int kNL = 32;
+// The rows of the pruned scans belong to NODES (lane group g of pass `it` owns node 1 + (it * nthr + tid) / 8 for the whole
+// kernel), so a lane's four list entries per row -- entries m, m + 8 (level 0) and 16 + m, 24 + m (level 1) of its node's
+// list -- are four bytes of ONE register per pass, loaded once at kernel start: no memory access for the ids in a scan,
+// and the first reads of a row (its position, the distances to its list entries and their positions) are independent.
+constexpr int kNlPasses = 4;             // 8 (n - 1) tasks over >= 256 (n <= 127) / >= 512 (n <= 255) threads
+struct NlWords {
+    unsigned w0, w1, w2, w3;             // (plain members: an indexed array ends up in scratch memory)
+    __device__ __forceinline__ unsigned of(int it) const {           // `it` is wave-uniform
+        return it == 0 ? w0 : it == 1 ? w1 : it == 2 ? w2 : w3;
+    }
+};
 constexpr int kPruneMinNodes = 80;       // 2-opt scan pruned from here up (same-box A/B at n = 66 .. 127), relocate from n = 128
 
 template <class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
-                                                        const uint8_t *nl_id, int n,
+                                                        const NlWords &nlw, int n,
                                                         int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
     const PlainDist<S> f{s};
     const int tasks = 8 * (n - 1);                           // 8 lanes per tour row, two list entries per lane and level
     const int rowbit = (lane & 56) + 7;                      // lane that holds entries 15 / 31 of this lane's row
-    for (int task0 = 0; task0 < tasks; task0 += nthr) {      // wave-uniform trip count; a wavefront's tasks are whole rows
+    int it = 0;
+    for (int task0 = 0; task0 < tasks; task0 += nthr, ++it) {      // wave-uniform trip count; a wavefront's tasks are whole rows
         const int task = task0 + tid;
         const bool live = task < tasks;
-        const int p = 1 + (live ? task >> 3 : 0), m = task & 7;
-        const int x = t[p], xm = t[p - 1], xp = t[p + 1];
+        // the row of NODE x (every node but the depot has one), wherever it sits in the tour: p = pos[x]
+        const int x = 1 + (live ? task >> 3 : 0), m = task & 7;
+        const unsigned ids4 = nlw.of(it);
+        const int p = pos[x];
+        const int xm = t[p - 1], xp = t[p + 1];
         const double ep = Ef[p], es = Ef[p + 1];             // D[x, t[p-1]], D[x, t[p+1]]
         const double thr = ep > es ? ep : es;
         bool more = live;                                    // the row may hold candidates among its next 16 list entries
 #pragma unroll 1
         for (int lvl = 0; lvl < 2; ++lvl) {
-            const uint8_t *ids = nl_id + (size_t)x * kNL + lvl * 16 + m;
-            const int y0 = ids[0], y1 = ids[8];              // entries m and m + 8 of this level
+            const int y0 = (ids4 >> (16 * lvl)) & 0xff, y1 = (ids4 >> (16 * lvl + 8)) & 0xff;     // entries m and m + 8 of this level
             const double d0 = s.dist(x, y0), d1 = s.dist(x, y1);
             const int q0 = pos[y0], q1 = pos[y1];
             bool last = false;
@@ -969,17 +983,19 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
 
 template <class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
-                                                         const uint8_t *nl_id, int n, double Lcap,
+                                                         const NlWords &nlw, int n, double Lcap,
                                                          const int *longk, int nlong,
                                                          int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
     const PlainDist<S> f{s};
     const int tasks = 8 * (n - 1);
     const int rowbit = (lane & 56) + 7;
-    for (int task0 = 0; task0 < tasks; task0 += nthr) {
+    int it = 0;
+    for (int task0 = 0; task0 < tasks; task0 += nthr, ++it) {
         const int task = task0 + tid;
         const bool live = task < tasks;
-        const int p = 1 + (live ? task >> 3 : 0), m = task & 7;
-        const int b = t[p];
+        const int b = 1 + (live ? task >> 3 : 0), m = task & 7;      // the row of NODE b, at tour position p
+        const unsigned ids4 = nlw.of(it);
+        const int p = pos[b];
         double base = -Ef[p];                                    // -D[a,b]          (operators.py:97-99, left to right)
         base = base - Ef[p + 1];                                 // -D[b,c]
         base = base + s.dist(t[p - 1], t[p + 1]);                // +D[a,c]
@@ -1003,8 +1019,7 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
         bool more = live;
 #pragma unroll 1
         for (int lvl = 0; lvl < 2; ++lvl) {
-            const uint8_t *ids = nl_id + (size_t)b * kNL + lvl * 16 + m;
-            const int y0 = ids[0], y1 = ids[8];
+            const int y0 = (ids4 >> (16 * lvl)) & 0xff, y1 = (ids4 >> (16 * lvl + 8)) & 0xff;
             const double d0 = s.dist(b, y0), d1 = s.dist(b, y1);
             const int q0 = pos[y0], q1 = pos[y1];
             // y = t[q] is d of target edge k1 = q and e of target edge k2 = q - 1 (the depot closes the tour: e = t[n])
@@ -1489,7 +1504,7 @@ struct Trace<false> {
 
 // neighbour lists of the pruned descent scans for this instance (on = false: the full scans run); ppos = node -> position
 struct PruneCtx {
-    const uint8_t *id; bool on;
+    NlWords nlw; bool on;
 };
 
 template <class S, bool FI, int GP, class TT, class TRC>
@@ -1570,9 +1585,9 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 #else
                     long long *dbg = nullptr;
 #endif
-                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, tid, nthr, lane, bd, bk, dbg);
+                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.nlw, n, tid, nthr, lane, bd, bk, dbg);
                     else if constexpr (kPruneRelocate)
-                        scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.id, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
+                        scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
                     lean = true;
                 }
             }
@@ -1712,8 +1727,22 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
     if (!FI && nthr > kWave) { block_reduce_lds_init(ctl, tid); __syncthreads(); }
     STAMP_BEGIN();
-    PruneCtx pc{nullptr, false};
-    if (A.nl_id && A.prune_ok[b]) { pc.id = A.nl_id + (size_t)b * n * kNL; pc.on = true; }
+    PruneCtx pc{{0u, 0u, 0u, 0u}, false};
+    if constexpr (!FI && S::kSymmetric) {
+        // (a workgroup too small to hold its rows' list words in kNlPasses registers per lane runs the full scans)
+        if (A.nl_id && A.prune_ok[b] && 8 * (n - 1) <= kNlPasses * nthr) {
+            const uint8_t *nl = A.nl_id + (size_t)b * n * kNL;
+            auto word = [&](int it) -> unsigned {
+                const int task = it * nthr + tid;
+                if (task >= 8 * (n - 1)) return 0u;
+                const uint8_t *r = nl + (size_t)(1 + (task >> 3)) * kNL + (task & 7);
+                return (unsigned)r[0] | ((unsigned)r[8] << 8) | ((unsigned)r[16] << 16) | ((unsigned)r[24] << 24);
+            };
+            static_assert(kNlPasses == 4, "NlWords has four members");
+            pc.nlw.w0 = word(0); pc.nlw.w1 = word(1); pc.nlw.w2 = word(2); pc.nlw.w3 = word(3);
+            pc.on = true;
+        }
+    }
     local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
