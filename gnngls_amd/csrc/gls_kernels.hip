@@ -1611,6 +1611,9 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 if (op == 0) scan_two_opt_a2a<S, FI, TT, S::kScanUnroll>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                 else         scan_relocate_a2a<S, FI, TT, S::kScanUnroll>(s, t, Ef, n, wave, nwaves, lane, bd, bk);
             }
+#ifdef GLS_STAMPS
+            if (!kPruneRelocate && op == 1) st.acc[15] += clock64() - st.t0;       // relocate's share of the scan cycles (GP = 2 builds)
+#endif
             STAMP_END(8);    // a2a scan (this wave's share)
             if (!FI && nwaves > 1) block_reduce_best_lds(ctl, phase, tid, bd, bk);
             else block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);

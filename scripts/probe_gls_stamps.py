@@ -59,6 +59,8 @@ simd = [((raw[:, 7] >> (8 * w)) & 0xff) - 1 for w in range(4)]
 import collections
 print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.tolist() for x in simd])).most_common(6))
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
+if n < 128 and per_wave[4] > 0:
+    print(f"descent scans of wavefront 0: relocate {per_wave[4] / max(sc / 2, 1):.0f} cycles per scan, 2-opt {(st[8] - per_wave[4]) / max(sc / 2, 1):.0f}")
 if int(os.environ.get("TEAM", "-1")) == 0 and per_wave[:4].sum() > 0:
     print(f"pruned scans (wavefront 0): overflow rows per scan 2-opt {per_wave[0] / max(sc / 2, 1):.2f}, relocate {per_wave[1] / max(sc / 2, 1):.2f}; "
           f"wave-passes per scan {per_wave[2] / max(sc / 2, 1):.2f} / {per_wave[3] / max(sc / 2, 1):.2f}")
