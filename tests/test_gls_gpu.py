@@ -208,6 +208,31 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
         assert_bits(r.imp_cost[b, :o["imp_len"]].cpu().numpy(), o["imp_cost"])
 
 
+def test_gls_halved_workgroups_with_prune_lists_vs_oracle(ops):
+    """n = 84 with more instances than 4-wave workgroups keep resident: the launcher halves the workgroup to 128 threads;
+    a lane would then need more than the four list registers the pruned scans keep per lane (8 (n - 1) rows x lanes over
+    128 threads = 6 passes), so such a launch runs the full scans although the neighbour lists were built.  Sampled
+    instances against the oracle, bit for bit."""
+    from oracle import gls_oracle as go
+    n, B, K = 84, 1100, 2
+    cfg = ops.gls_describe_config(n, B)
+    assert cfg["store"] == "compact" and cfg["threads"] == 128
+    rng = np.random.default_rng(84)
+    D, _ = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    gd = d[None].contiguous()
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, max_outer_iters=K, trace_cap=0)
+    assert (r.status == 0).all()
+    init_h, cost_h = init.cpu().numpy(), cost.cpu().numpy()
+    for b in (0, 1, 511, 1024, 1099):
+        o = go.guided_local_search(D[b], D[b][None], init_h[b], cost_h[b], perturbation_moves=20, max_outer_iters=K)
+        assert r.best_tour[b].cpu().tolist() == o["best_tour"]
+        assert_bits(r.best_cost[b].item(), o["best_cost"])
+        assert int(r.evals[b]) == o["evals"]
+
+
 def test_gls_global_store_fallback(ops):
     """n too large for the LDS triangles -> global-memory store path; same results as the oracle."""
     from oracle import gls_oracle as go
