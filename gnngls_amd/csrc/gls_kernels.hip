@@ -883,6 +883,135 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
     }
 }
 
+// ---- lean scans on the two 32-lane halves of ONE wavefront (single-wavefront workgroups, n <= 33: TSP20) ------------------
+// With at most 32 rows the upper half of the wavefront idles in the scans above.  Here lane (h, l) = (lane >> 5, lane & 31)
+// owns row 1 + l in both halves and half h walks half of the other index (relocate: target edges k, 2-opt: j), so a scan
+// takes half the steps.  The node of a step is no longer wave-uniform: two v_readlane and a select per step, and its row
+// address is vector arithmetic.  Same deltas (same operands, same order), same keys; within a lane the keys still ascend.
+#ifndef GLS_HALF_SCANS
+#define GLS_HALF_SCANS 1
+#endif
+constexpr int kHalfScanMinNodes = 8, kHalfScanMaxNodes = 33;
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_relocate_a2a_lean_half(const S &s, const TT *t, const double *Ef, int n, int lane,
+                                                            double &bd, int &bk) {
+    const bool hi = lane >= 32;
+    const int tl = t[lane <= n ? lane : n];                  // tour position `lane` (n <= 33: one register per lane)
+    const int K0 = (n + 1) >> 1;                             // half 0: k = 0 .. K0-1; half 1: k = K0 .. n-1
+    const int kofs = hi ? K0 : 0;
+    const int i = 1 + (lane & 31);
+    const bool row_ok = i <= n - 1;                          // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
+    const int ic = row_ok ? i : 1;
+    const int a = t[ic - 1], b = t[ic], cc = t[ic + 1];
+    double base = -Ef[ic];                                   // -D[a,b]
+    base = base - Ef[ic + 1];                                // -D[b,c]
+    base = base + s.dist(a, cc);                             // +D[a,c]
+    if (!row_ok) base = __builtin_inf();                     // delta = +inf: never below the best (bd <= 0)
+    const int b2 = (b * (b - 1)) >> 1;
+    const int dbase = lds_byte_addr(s.d);
+    const int bx = opaque_vgpr(dbase + 8 * b2), b8 = opaque_vgpr(8 * b);      // b = t[i] >= 1
+    const int d0a = bcast_int(tl, 0), d0b = bcast_int(tl, K0);
+    const int d0 = hi ? d0b : d0a;                           // t[k] of the half's first step
+    double vd = s.dist_at(s.idx2(b, b2, d0, (d0 * (d0 - 1)) >> 1));           // D[t[k0], b]   (garbage, unused, where t[k0] == b)
+    const int efb = opaque_vgpr(lds_byte_addr(Ef) + 8 * kofs);                // address of Ef[k] of the half's first step
+    const int live1 = n - K0;                                // steps of half 1 (K0, or K0 - 1 for odd n)
+    auto group = [&](int ss, auto ucount, auto safe_addr) {
+        constexpr int U = decltype(ucount)::value;
+        constexpr bool SAFE = decltype(safe_addr)::value;    // a step of the group may meet node 0 (k = n-1: t[n]) or be idle in half 1
+        double ve[U], de[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e0 = bcast_int(tl, ss + u + 1), e1 = bcast_int(tl, ss + u + 1 + K0);
+            const int e = hi ? e1 : e0;                      // t[k+1]
+            de[u] = lds_read_f64(efb + 8 * (ss + u + 1));    // D[t[k], t[k+1]]
+            const int fast = tri_addr_max(bx, b8, dbase + 4 * e * (e - 1), 8 * e);
+            ve[u] = lds_read_f64(SAFE ? (e == 0 ? bx : fast) : fast);         // D[b, t[k+1]]; D[b, 0] is the first entry of row b
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = ss + u + kofs;
+            double delta = base - de[u];                     // -D[d,e]          (operators.py:100-102, left to right)
+            delta = delta + vd;                              // +D[d,b]
+            delta = delta + ve[u];                           // +D[b,e]
+            vd = ve[u];
+            if (SAFE && hi && ss + u >= live1) delta = __builtin_inf();
+            if (delta < bd) {
+                rare_path();
+                // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
+                if ((unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
+            }
+        }
+    };
+    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using U1 = std::integral_constant<int, 1>;
+    using FAST = std::integral_constant<bool, false>;
+    using SAFE = std::integral_constant<bool, true>;
+    int ss = 0;
+    for (; ss + GLS_LEAN_UNROLL <= K0 - 2; ss += GLS_LEAN_UNROLL) group(ss, UN{}, FAST{});
+    for (; ss < K0 - 2; ++ss) group(ss, U1{}, FAST{});
+    for (; ss < K0; ++ss) group(ss, U1{}, SAFE{});           // the last two steps: node 0 closes the tour; odd n: half 1 is one short
+}
+
+template <class S, class TT>
+__device__ __forceinline__ void scan_two_opt_a2a_lean_half(const S &s, const TT *t, const double *Eb, int n, int lane,
+                                                           double &bd, int &bk) {
+    // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39): rows i = 1..n-3, j = 3..n-1 (j >= i + 2 checked late)
+    const bool hi = lane >= 32;
+    const int tl = t[lane <= n ? lane : n];
+    const int cnt = n - 3, J0 = (cnt + 1) >> 1;              // half 0: j = 3 .. 2+J0; half 1: j = 3+J0 .. n-1
+    const int jofs = hi ? J0 : 0;
+    const int i = 1 + (lane & 31);
+    const bool row_ok = i <= n - 3;
+    const int ic = row_ok ? i : 1;
+    const int a = t[ic], b = t[ic - 1];
+    const int a2 = (a * (a - 1)) >> 1, b2 = (b * (b - 1)) >> 1;
+    const double eab = row_ok ? Eb[ic] : -__builtin_inf();   // D[a,b]; rows past the end: delta = +inf, never below the best
+    const int dbase = lds_byte_addr(s.d);
+    const int ax = opaque_vgpr(dbase + 8 * a2), a8 = opaque_vgpr(8 * a);      // a = t[i] >= 1; c = t[j] >= 1 and d = t[j-1] >= 1 (j >= 3)
+    const int bx = opaque_vgpr(b == 0 ? kNoRow : dbase + 8 * b2), b8 = opaque_vgpr(8 * b);   // b = t[i-1] is node 0 on row 1
+    const int da = bcast_int(tl, 2), db = bcast_int(tl, 2 + J0);
+    int d = hi ? db : da;                                    // t[j-1] of the half's first step
+    int d2 = dbase + 4 * d * (d - 1);
+    const int ebb = opaque_vgpr(lds_byte_addr(Eb) + 8 * jofs);
+    const int live1 = cnt - J0;                              // steps of half 1 (J0, or J0 - 1 for odd n - 3)
+    auto group = [&](int ss, auto ucount, auto tail) {
+        constexpr int U = decltype(ucount)::value;
+        constexpr bool TAIL = decltype(tail)::value;
+        double vac[U], vbd[U], ecd[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c0 = bcast_int(tl, 3 + ss + u), c1 = bcast_int(tl, 3 + ss + u + J0);
+            const int c = hi ? c1 : c0;                      // t[j]
+            ecd[u] = lds_read_f64(ebb + 8 * (3 + ss + u));   // D[c,d]
+            const int c2 = dbase + 4 * c * (c - 1);
+            vac[u] = lds_read_f64(tri_addr_max(ax, a8, c2, 8 * c));      // D[a,c]
+            vbd[u] = lds_read_f64(tri_addr_max(bx, b8, d2, 8 * d));      // D[b,d]
+            d = c; d2 = c2;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = 3 + ss + u + jofs;
+            double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
+            delta = delta - eab;
+            delta = delta - ecd[u];
+            if (TAIL && hi && ss + u >= live1) delta = __builtin_inf();
+            if (delta < bd) {
+                rare_path();
+                if (j >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j); }
+            }
+        }
+    };
+    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using U1 = std::integral_constant<int, 1>;
+    using BODY = std::integral_constant<bool, false>;
+    using TAIL = std::integral_constant<bool, true>;
+    int ss = 0;
+    for (; ss + GLS_LEAN_UNROLL <= J0 - 1; ss += GLS_LEAN_UNROLL) group(ss, UN{}, BODY{});
+    for (; ss < J0 - 1; ++ss) group(ss, U1{}, BODY{});
+    for (; ss < J0; ++ss) group(ss, U1{}, TAIL{});           // odd n - 3: half 1 is one step short
+}
+
 // ---- pruned a2a scans (best improvement, symmetric stores; 2-opt from n = 80, relocate from n = 128) -------------------
 // The descent needs, per scan, the lexicographic minimum of (delta, i, j) over the moves that qualify (delta < 0 and not
 // np.isclose(0, delta), operators.py:42).  Any SUPERSET of the qualifying moves gives the same minimum, and most of the
@@ -1597,6 +1726,11 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 // positions 0..n fit 2 (n <= 127) or 4 (n <= 255) register slots per lane; every block of 64 rows needs
                 // a wavefront of its own
                 // (GP = register slots of the perturbation phase = the same 2 / 4, chosen by the launcher from n)
+                if (GLS_HALF_SCANS && GP == 1 && !lean && nwaves == 1 && n >= kHalfScanMinNodes && n <= kHalfScanMaxNodes) {
+                    if (op == 0) scan_two_opt_a2a_lean_half<S, TT>(s, t, Eb, n, lane, bd, bk);
+                    else         scan_relocate_a2a_lean_half<S, TT>(s, t, Ef, n, lane, bd, bk);
+                    lean = true;
+                }
                 if (!lean && nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
                     if (op == 0) scan_two_opt_a2a_lean<GP, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                     else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
@@ -2137,6 +2271,13 @@ static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStr
 
 template <class S, bool FI, int WPS, bool TEAM>
 static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    // small instances on single-wavefront workgroups (TSP20): the one-slot instantiation, whose descent scans use both
+    // 32-lane halves of the wavefront (scan_*_a2a_lean_half) -- an instantiation of its own so that the register
+    // allocation of the others (the TSP100 headline runs on GP = 2) does not see that code
+    if constexpr (!FI && !TEAM && WPS == 4 && S::kSymmetric && sizeof(typename S::pen_t) == 4) {
+        if (GLS_HALF_SCANS && A.n >= kHalfScanMinNodes && A.n <= kHalfScanMaxNodes && threads == kWave)
+            return launch_gls_g<S, FI, 1, WPS, TEAM>(A, lds, threads, stream);
+    }
     // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover positions 0..n for n <= 127
     if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2, WPS, TEAM>(A, lds, threads, stream);
     return launch_gls_g<S, FI, kGuidePassesMax, WPS, TEAM>(A, lds, threads, stream);
