@@ -891,6 +891,9 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
 #ifndef GLS_HALF_SCANS
 #define GLS_HALF_SCANS 1
 #endif
+#ifndef GLS_HALF_UNROLL
+#define GLS_HALF_UNROLL 3             // steps per group of the half-wave scans (4: 2 % faster at TSP20, 8 B of scratch)
+#endif
 constexpr int kHalfScanMinNodes = 8, kHalfScanMaxNodes = 33;
 
 template <class S, class TT>
@@ -943,12 +946,12 @@ __device__ __forceinline__ void scan_relocate_a2a_lean_half(const S &s, const TT
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using UN = std::integral_constant<int, GLS_HALF_UNROLL>;
     using U1 = std::integral_constant<int, 1>;
     using FAST = std::integral_constant<bool, false>;
     using SAFE = std::integral_constant<bool, true>;
     int ss = 0;
-    for (; ss + GLS_LEAN_UNROLL <= K0 - 2; ss += GLS_LEAN_UNROLL) group(ss, UN{}, FAST{});
+    for (; ss + GLS_HALF_UNROLL <= K0 - 2; ss += GLS_HALF_UNROLL) group(ss, UN{}, FAST{});
     for (; ss < K0 - 2; ++ss) group(ss, U1{}, FAST{});
     for (; ss < K0; ++ss) group(ss, U1{}, SAFE{});           // the last two steps: node 0 closes the tour; odd n: half 1 is one short
 }
@@ -1002,12 +1005,12 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean_half(const S &s, const TT 
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using UN = std::integral_constant<int, GLS_HALF_UNROLL>;
     using U1 = std::integral_constant<int, 1>;
     using BODY = std::integral_constant<bool, false>;
     using TAIL = std::integral_constant<bool, true>;
     int ss = 0;
-    for (; ss + GLS_LEAN_UNROLL <= J0 - 1; ss += GLS_LEAN_UNROLL) group(ss, UN{}, BODY{});
+    for (; ss + GLS_HALF_UNROLL <= J0 - 1; ss += GLS_HALF_UNROLL) group(ss, UN{}, BODY{});
     for (; ss < J0 - 1; ++ss) group(ss, U1{}, BODY{});
     for (; ss < J0; ++ss) group(ss, U1{}, TAIL{});           // odd n - 3: half 1 is one step short
 }
