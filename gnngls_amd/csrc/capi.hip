@@ -117,7 +117,7 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch) {
         if (done) return;
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
-        int threads = gnngls::gls_block_threads(n, store);
+        int threads = gnngls::gls_block_threads(n, store, bits);
         // compact store, batch larger than the 128-VGPR build keeps resident at the default workgroup size: halve the
         // workgroup (down to the wavefronts the lean scans need, one per block of 64 rows) before falling back to the
         // 64-VGPR build -- TSP50 x 2048 on 2-wave workgroups at 128 VGPRs: 6.2k outer iterations per second vs 5.6k on

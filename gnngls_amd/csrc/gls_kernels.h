@@ -44,7 +44,7 @@ struct GlsArgs {
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
 size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false);
-int gls_block_threads(int n, int store);
+int gls_block_threads(int n, int store, int penalty_bits = 32);
 void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 // resident wavefronts per SIMD (= register budget) of the kernel instantiation for this configuration: 4 or 8 for the
 // compact store, fixed for the others

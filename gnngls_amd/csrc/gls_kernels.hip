@@ -2215,10 +2215,15 @@ size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team) {
 static std::atomic<int> g_threads_override{0};      // experiments only (gnngls_debug_set_gls_threads)
 void gls_set_block_threads_override(int threads) { g_threads_override.store(threads, std::memory_order_relaxed); }
 
-int gls_block_threads(int n, int store) {
+int gls_block_threads(int n, int store, int penalty_bits) {
     const int forced = g_threads_override.load(std::memory_order_relaxed);
     if (forced > 0) return forced;
     if (n <= 24) return 64;
+    // n <= 33 on the stores that have the half-wave descent scans: ONE wavefront using both its 32-lane halves beats two
+    // wavefronts sharing the lean scans (outer iterations in 2 s, x 1000, noise guide: n = 26 24.2k -> 25.7k, n = 30 22.6k ->
+    // 24.1k, n = 33 21.1k -> 22.4k)
+    if (GLS_HALF_SCANS && n <= kHalfScanMaxNodes && penalty_bits == 32 && (store == GLS_STORE_COMPACT || store == GLS_STORE_TRI))
+        return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
     // compact store with the lean descent scans (n <= 127), four workgroups per CU, measured at TSP100 x 1024 (outer
