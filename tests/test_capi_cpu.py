@@ -102,6 +102,9 @@ def test_gls_store_selection(lib):
     assert ops.gls_resident_capacity(100) == 1024 and ops.gls_resident_capacity(50) == 2048
     assert ops.gls_describe_config(50, 1024)["per_cu"] >= 4 and ops.gls_describe_config(50, 2048)["per_cu"] == 8
     assert ops.gls_describe_config(20, 1000)["threads"] == 64 and ops.gls_describe_config(20, 1000)["per_cu"] >= 4
+    # single-wavefront workgroups up to n = 33 where the half-wave descent scans exist (32-bit counters), two wavefronts above
+    assert ops.gls_describe_config(30, 1000)["threads"] == 64 and ops.gls_describe_config(33, 1000)["threads"] == 64
+    assert ops.gls_describe_config(34, 1000)["threads"] == 128 and ops.gls_describe_config(30, 1000, penalty_bits=16)["threads"] == 128
     assert ops.gls_describe_config(100, 512)["store"] == "lds-tri-i32" and ops.gls_describe_config(100, 512)["per_cu"] == 2
     assert ops.gls_describe_config(100, 513)["store"] == "compact"            # 16-bit LDS counters only on request
     assert ops.gls_describe_config(100, 700, penalty_bits=16) == {"store": "lds-tri-u16", "threads": 512, "lds_bytes": 51776, "per_cu": 3, "team": False, "waves_per_simd": 6}
