@@ -17,6 +17,10 @@
 //     t[i], t[i-1] and the row constants are wave-uniform, tour reads are conflict-free and each
 //     evaluation costs two random LDS reads (the other terms are the per-position edge lengths
 //     Ef[], rebuilt in O(n) after every move);
+//     -- the generic form; the best-improvement descent (the reference's default) runs on specialised scans with the
+//     same deltas and keys: lean scans (a tour row per lane, the other index wave-uniform), on both 32-lane halves of the
+//     wavefront for single-wavefront workgroups (n <= 33), and from n = 80 (2-opt) / n = 128 (relocate) pruned scans that
+//     only evaluate the moves that can qualify (32-nearest-neighbour lists, rows owned by nodes: exact, see there);
 //   * best-improvement selection is an arg-min on the key (delta, i, j): identical to the
 //     reference's sequential strict-< scan (first minimum in enumeration order wins); inside a
 //     wavefront it is three 32-bit DPP min-reductions, no LDS-crossbar shuffles;
