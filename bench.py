@@ -45,6 +45,11 @@ PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 PEAK_LDS_GBS = 150000.0          # MI355X_MICROARCH.md: aggregate ds_read_b64 rate, every CU streaming
 BLOCK = 1024                     # instances per seeded block
+N_SIMDS, N_CUS = 1024, 256       # MI355X: 256 CUs x 4 SIMDs
+GAP_GRID_S = (0.1, 0.3, 1.0, 3.0)   # search seconds at which the gap-versus-budget record is read (+ the end of the budget)
+IMP_CAP = 256                    # improvement-trace entries kept per instance (a 10 s TSP100 search improves its best a few dozen times)
+ISO_ROUNDS = 10                  # device loads that share ONE time limit in the iso-quality pass
+COUNT_PASS_S = 2.0               # length of the untimed pass that measures executed / reference-equivalent evaluations
 
 
 def parse():
@@ -69,6 +74,8 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_cores", type=int, default=0, help="host cores of the CPU baseline (0 = all)")
     ap.add_argument("--best_known", default=None, help="best-known file (default: bench_data/best_known_tsp{n}_seed{seed}.npz)")
+    ap.add_argument("--no_iso_quality", action="store_true",
+                    help="skip the untimed iso-quality pass (ISO_ROUNDS device loads sharing ONE time limit; rank 0, N = 1 only)")
     ap.add_argument("--no_gap_bracket", action="store_true",
                     help="skip the Held-Karp 1-tree lower bounds (oracle/one_tree.c, host cores, after the timed region)")
     ap.add_argument("--exact_gap", action="store_true",
@@ -104,6 +111,114 @@ def load_best_known(path, n, seed, lo, hi):
     if np.isnan(out).any():
         return None, "best-known file does not cover these instance blocks"
     return out, f"{os.path.relpath(path, ROOT)}: {str(z['how'])}"
+
+
+def best_at_times(imp_cost, imp_time, imp_len, init_cost, grid):
+    """Search-progress record -> best tour length known at each search time of `grid` (test.py:97-117: best_cost = cummin
+    over the progress rows, dt = time since the start).  imp_cost / imp_time [B, cap]: the returned best after every
+    improvement and its time in seconds since the search started, imp_len [B] entries written (the last valid one is the
+    terminal entry = state at the end of the search; see include/gnngls_hip.h), init_cost [B] = the start tour, which is all
+    that exists before the first entry.  -> (best [B, len(grid)], truncated [B] bool: improvements beyond the buffer were
+    dropped, so values between the last kept improvement and the end of the search are upper bounds)."""
+    imp_cost, imp_time = np.asarray(imp_cost, dtype=np.float64), np.asarray(imp_time, dtype=np.float64)
+    B, cap = imp_cost.shape
+    valid = np.arange(cap)[None, :] < np.minimum(np.asarray(imp_len), cap)[:, None]
+    out = np.empty((B, len(grid)))
+    for g, t in enumerate(grid):
+        m = valid & (imp_time <= t)
+        c = np.where(m, imp_cost, np.inf).min(axis=1) if cap else np.full(B, np.inf)
+        out[:, g] = np.minimum(c, np.asarray(init_cost, dtype=np.float64))
+    return out, np.asarray(imp_len) > cap
+
+
+def gap_curve_sums(best_t, best_known):
+    """-> [G, 3] (sum of gaps in percent, instances at the best-known length, instances): additive over ranks."""
+    gap = (best_t / best_known[:, None] - 1.0) * 100.0
+    return np.stack([gap.sum(axis=0), (np.abs(gap) <= 1e-9).sum(axis=0).astype(np.float64),
+                     np.full(gap.shape[1], float(gap.shape[0]))], axis=1)
+
+
+def gap_curve(sums, grid, pre_search_s):
+    """[G, 3] sums -> the gap_vs_budget list of the bench line.  t_s = seconds of SEARCH; the reference's budget clock
+    (test.py:64 starts it before the forward pass) reads t_s + pre_search_s at that moment."""
+    return [{"t_s": float(t), "budget_t_s": float(t + pre_search_s), "mean_gap_pct": float(sg / max(cnt, 1.0)),
+             "at_best_known_pct": float(100.0 * ab / max(cnt, 1.0))} for t, (sg, ab, cnt) in zip(grid, sums)]
+
+
+def physical_cores():
+    """(physical cores, hardware threads) of the host from /proc/cpuinfo (unique (physical id, core id) pairs)."""
+    pairs, threads, phys = set(), 0, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+    except OSError:
+        pass
+    threads = threads or (os.cpu_count() or 1)
+    return (len(pairs) or threads), threads
+
+
+def search_roofline(n, steps, gls_ms, gls_launches, ref_evals, exec_ratio, resident, traffic, workload):
+    """Roofline object of the search kernel (the kernel that owns the timed step).
+
+    What binds gls_kernel is vector-instruction issue: the primary fraction is the measured busy
+    fraction of the vector ALUs -- a counter ratio, <= 1 by construction -- from the committed PMC passes on this workload
+    (profiles/traffic_r0*.json; `pmc.workload` says what they were collected on).  Measured in this run, per launch, from
+    the HIP events around the timed launches and the kernel's own counters: the reference-equivalent evaluation rate (every
+    move the reference's scans evaluate, SURVEY 8d -- what rounds 1-3 were compared on: a work rate, not a physical
+    fraction), and the EXECUTED rate = that x exec_ratio, the executed / reference-equivalent evaluations of a short untimed
+    pass of the same workload on the counting instantiation of the kernel (the pruned descent scans only evaluate the moves
+    that can qualify; None = not available for this configuration).  `lds_executed` = algorithmic LDS bytes of the executed
+    evaluations against the aggregate LDS rate: <= 1 by construction, every executed evaluation reads at least these bytes."""
+    n2 = (n - 2) * (n - 3) / 2.0
+    nr = float((n - 2) * (n - 2))
+    lds_bytes_per_eval = (48.0 * n2 + 68.0 * nr) / (n2 + nr)                # SURVEY 8(d): 48 B / 68 B per evaluation
+    avg_launch_s = gls_ms / max(gls_launches, 1) * 1e-3
+    launches_per_step = max(int(gls_launches) // max(steps, 1), 1)
+    per_launch = lambda evals: evals / launches_per_step / avg_launch_s if avg_launch_s > 0 else 0.0   # noqa: E731
+    ref_rate = per_launch(ref_evals)
+    exec_rate = ref_rate * exec_ratio if exec_ratio is not None else None
+    busy = {k[:-len("_busy_frac")]: traffic[k] for k in traffic if k.endswith("_busy_frac") and traffic[k] is not None}
+    order = sorted(busy, key=busy.get, reverse=True)
+    clock = traffic.get("clock_ghz")
+    valu = busy.get("valu")
+    out = {
+        "kernel": "gls_kernel", "bound": "valu_issue",
+        # busy vector-ALU cycles per second over all SIMDs against the SIMD cycles per second (PMC: SQ_ACTIVE_INST_VALU x 4)
+        "achieved": valu * N_SIMDS * clock if valu is not None and clock else None,
+        "peak": N_SIMDS * clock if clock else None, "unit": "G SIMD-cycles/s",
+        "frac": valu,
+        "traffic": traffic["hbm_bytes_per_instance_second"] * resident * avg_launch_s
+        if "hbm_bytes_per_instance_second" in traffic else None,
+        "avg_launch_ms": avg_launch_s * 1e3, "launches": int(gls_launches), "resident_instances": resident,
+        "executed_evals_per_s": exec_rate, "reference_equivalent_evals_per_s": ref_rate,
+        "prune_ratio": exec_ratio,
+        "lds_bytes_per_eval": lds_bytes_per_eval,
+        "lds_executed": {"achieved": exec_rate * lds_bytes_per_eval / 1e9, "peak": PEAK_LDS_GBS, "unit": "GB/s",
+                         "frac": exec_rate * lds_bytes_per_eval / 1e9 / PEAK_LDS_GBS} if exec_rate is not None else None,
+        "reference_equivalent_frac": ref_rate * lds_bytes_per_eval / 1e9 / PEAK_LDS_GBS,
+        "delta_evals_per_s": ref_rate,
+        "pmc": {k: traffic[k] for k in ("valu_busy_frac", "lds_busy_frac", "lds_bank_conflict_frac", "wave_wait_frac",
+                                        "valu_insts_per_s", "lds_insts_per_s", "hbm_gbs", "clock_ghz", "workload", "source")
+                if k in traffic},
+        # the busiest pipes according to those counters (null without counters)
+        "binding_resource": {"name": (order[0] + "_issue") if order else None, "frac": busy[order[0]] if order else None,
+                             "second": order[1] if len(order) > 1 else None,
+                             "second_frac": busy[order[1]] if len(order) > 1 else None},
+        "pmc_matches_workload": bool(traffic.get("workload")) and all(traffic["workload"].get(k) == v for k, v in workload.items()),
+        "note": "frac = busy fraction of the vector ALUs (committed PMC passes, `pmc`).  reference_equivalent_evals_per_s is "
+                "measured on the timed launches (HIP events + the kernel's counter of what the reference evaluates); prune_ratio = "
+                "executed / reference-equivalent evaluations of a %g s untimed pass of the same workload on the counting "
+                "instantiation of the kernel (the pruned descent scans -- 2-opt from n = 80, relocate from n = 128 -- evaluate only "
+                "the moves that can qualify); executed_evals_per_s and lds_executed are their product.  reference_equivalent_frac = "
+                "the algorithmic LDS figure of rounds 1-3 (a work rate: 1 / prune_ratio above the executed one).  The forward "
+                "kernels' MFMA / HBM rooflines are under `kernels`" % COUNT_PASS_S,
+    }
+    return out
 
 
 def kernel_rooflines(prof, n, B_chunk, n_layers):
@@ -153,7 +268,7 @@ def load_traffic():
     """HBM traffic from the committed PMC passes (profiles/traffic_r0*.json, newest first: FETCH_SIZE/WRITE_SIZE collected
     and corrected as MI355X_MICROARCH.md prescribes)."""
     merged = {}
-    for name in ("traffic_r01.json", "traffic_r02.json", "traffic_r03.json"):
+    for name in ("traffic_r01.json", "traffic_r02.json", "traffic_r03.json", "traffic_r04.json"):
         try:
             merged.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except (OSError, ValueError):
@@ -195,8 +310,27 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, co
     costs = np.array([o["best_cost"] for o in outs])
     gaps = (costs / best_known[:cores] - 1.0) * 100.0 if best_known is not None else None
     search = float(np.mean([o["search_s"] for o in outs]))
+    curve = None
+    if best_known is not None:
+        cap = max(len(o["imp_cost"]) for o in outs)
+        pad = lambda xs, fill: np.array([list(o[xs]) + [fill] * (cap - len(o[xs])) for o in outs])   # noqa: E731
+        grid = list(GAP_GRID_S) + [time_limit]
+        bt, trunc = best_at_times(pad("imp_cost", np.inf), pad("imp_time", np.inf), np.array([o["imp_len"] for o in outs]),
+                                  init_cost[:cores], [t for t in grid[:-1]] + [np.inf])
+        curve = [p for p in gap_curve(gap_curve_sums(bt, best_known[:cores]), grid, 0.0) if p["t_s"] <= time_limit]
+    phys, threads = physical_cores()
+    per_core = 1.0 / search
     return {"value": cores / wall, "unit": "instances/s", "cores": cores, "kind": "port",
-            "per_core_value": 1.0 / search,
+            "per_core_value": per_core,
+            # the same search-progress record as the GPU line's gap_vs_budget (the CPU leg is not charged the forward pass:
+            # its budget clock is its search clock)
+            "gap_vs_budget": curve,
+            # NOT measured: what the whole host would deliver if every physical core ran one instance at the measured
+            # per-core rate (the container's cgroup grants `cores` CPUs of the box's hardware threads) -- an upper bound for
+            # the CPU (no shared-cache / memory / clock effects), so gpu_value / this is the conservative GPU-vs-box ratio
+            "whole_box_estimate": {"physical_cores": phys, "hardware_threads": threads, "instances_per_s": per_core * phys,
+                                   "assumption": "per_core_value x physical cores, linear scaling, one single-threaded search per "
+                                                 "core (the reference is single-threaded, test.py:59); not measured"},
             "sample": f"{cores} TSP{D.shape[1]} instances of the same batch, one per core on all {available_cores()} CPUs "
                       f"available to this container (cgroup quota; the box has {os.cpu_count()} hardware threads), "
                       f"{time_limit:g} s search budget each (GNN forward not charged to the CPU), guides as on "
@@ -209,6 +343,38 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, co
             # (SURVEY.md section 6 / BASELINE.md section 2, TSP100): the C port above is ~1400x faster per core
             "reference_python_probe": {"outer_iters_per_instance_10s": 41, "delta_evals_per_s": 5.1e5,
                                        "instances_per_s_per_core": 0.1, "source": "BASELINE.md section 2"}}
+
+
+def iso_quality_pass(args, n, chunk, model, scalers, pipeline):
+    """Untimed extra pass (rank 0, N = 1): ISO_ROUNDS device loads of `chunk` instances searched within ONE time limit
+    (budget="per_batch": the rounds share it, each instance is searched for time_limit / rounds including its forward
+    pass) -- the throughput end of the budget-versus-quality trade, with the gap there to judge it.  This is the number
+    that moves with kernel speed: the headline's instances/s is residency / budget by construction."""
+    covered = 0                                          # leading instances of the seeded set with a best-known length
+    while load_best_known(args.best_known, n, args.seed, covered, covered + chunk)[0] is not None and covered < ISO_ROUNDS * chunk:
+        covered += chunk
+    rounds = covered // max(chunk, 1)
+    if rounds < 2:
+        return {"skipped": f"needs >= 2 device loads ({chunk} instances each) with best-known lengths; the file covers {covered}"}
+    total = rounds * chunk
+    Dh = instance_range(args.seed, n, 0, total)
+    bk, _ = load_best_known(args.best_known, n, args.seed, 0, total)
+    D = torch.from_numpy(Dh).cuda()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    r = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
+                             perturbation_moves=args.perturbation_moves, chunk=chunk, budget="per_batch")
+    best = r.best_cost.cpu().numpy()
+    wall = time.time() - t0
+    gap = (best / bk - 1.0) * 100.0
+    return {"instances": total, "rounds": rounds, "instances_per_round": chunk, "time_limit_s": args.time_limit,
+            "budget": "per_batch", "wall_s": wall, "instances_per_s": total / wall,
+            "mean_gap_pct": float(gap.mean()), "max_gap_pct": float(gap.max()),
+            "instances_at_reference_pct": float((np.abs(gap) <= 1e-9).mean() * 100.0),
+            "outer_iters_per_instance": float(r.outer_iters.double().mean()),
+            "forward_s": r.timing["forward_s"], "init_s": r.timing["init_s"], "search_s": r.timing["search_s"],
+            "how": f"{rounds} device loads of {chunk} instances (blocks 0.. of the seeded set) through solve_batch(budget='per_batch'): "
+                   f"ONE {args.time_limit:g} s limit for all of them, forward passes included; one untimed pass after the timed steps"}
 
 
 def shard_plan(total_instances, batch, world, rank):
@@ -281,7 +447,8 @@ def main():
     def step():
         nonlocal gathered
         r = pipeline.solve_batch(D, model, scalers, guides=args.guides, time_limit=args.time_limit,
-                                 perturbation_moves=args.perturbation_moves, chunk=chunk_eff, budget=args.budget)
+                                 perturbation_moves=args.perturbation_moves, chunk=chunk_eff, budget=args.budget,
+                                 imp_cap=IMP_CAP)
         local = torch.stack([r.best_cost, r.init_cost, r.outer_iters.double(), r.evals.double(),
                              r.status.double()], dim=1).contiguous()           # [B, 5] fp64
         if grouped and backend != "nccl":
@@ -294,11 +461,26 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # count the collectives the timed steps issue (the path has ONE per step: the gather; the barriers bracket the region)
+    collectives = {}
+    originals = {}
+    if grouped:
+        for name in ("gather", "all_gather", "all_gather_into_tensor", "all_reduce", "broadcast", "reduce_scatter", "all_to_all",
+                     "scatter", "reduce", "send", "recv"):
+            if hasattr(dist, name):
+                originals[name] = getattr(dist, name)
+
+                def counted(*a, _f=originals[name], _n=name, **k):
+                    collectives[_n] = collectives.get(_n, 0) + 1
+                    return _f(*a, **k)
+                setattr(dist, name, counted)
     _lib.profile_enable(True)
     t0 = time.time()
     last = None
     for _ in range(args.steps):
         last = step()
+    for name, f in originals.items():
+        setattr(dist, name, f)
     barrier()
     dt = time.time() - t0
     prof = _lib.profile_collect()
@@ -308,7 +490,36 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=stats_dev)
     # per-rank search-kernel statistics of the timed region (for the roofline of the whole job), summed / maxed below
     gls_ms, gls_launches = prof["gls"]
-    mine = torch.tensor([gls_ms, float(gls_launches), float(rounds)], dtype=torch.float64, device=stats_dev)
+    # gap-versus-budget record of this rank's instances (last timed step): best tour length known after t seconds of search,
+    # from the improvement trace the search kernel wrote (zero extra device time), against the best-known lengths
+    grid = list(GAP_GRID_S)
+    search_end = np.inf
+    if args.exact_gap:
+        bk_local, curve_reason = None, "exact optima are computed on rank 0 after the run"
+    else:
+        bk_local, curve_reason = load_best_known(args.best_known, n, args.seed, lo, hi)
+    curve_sums = np.zeros((len(grid) + 1, 3))
+    truncated = 0
+    pre_search_s = 0.0
+    if B > 0:
+        pre_search_s = float((last.launch_time - last.start_time).mean())
+        if bk_local is not None:
+            bt, trunc = best_at_times(last.imp_cost.cpu().numpy(), last.imp_time.cpu().numpy(), last.imp_len.cpu().numpy(),
+                                      last.init_cost.cpu().numpy(), grid + [search_end])
+            curve_sums = gap_curve_sums(bt, bk_local)
+            truncated = int(trunc.sum())
+    # executed-versus-reference evaluation ratio of the search kernel: one short UNTIMED pass of the same workload on the
+    # counting instantiation of the kernel (counting costs 2-3 %, so the timed steps never run it); rank 0 only
+    exec_ratio = -1.0
+    if rank == 0 and B > 0:
+        rc = pipeline.solve_batch(D[:min(chunk_eff, B)], model, scalers, guides=args.guides, time_limit=min(COUNT_PASS_S, args.time_limit),
+                                  perturbation_moves=args.perturbation_moves, count_executed=True)
+        if int(rc.evals_executed.min()) >= 0:
+            exec_ratio = float(rc.evals_executed.sum()) / max(float(rc.evals.sum()), 1.0)
+    mine = torch.tensor([gls_ms, float(gls_launches), float(rounds), exec_ratio,
+                         float(last.evals.sum()) if B > 0 else 0.0, float(truncated), pre_search_s * B,
+                         float(torch.cuda.current_device())]
+                        + curve_sums.reshape(-1).tolist(), dtype=torch.float64, device=stats_dev)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,20 +561,30 @@ def main():
                        "how": "mean over the instances of (best_cost / x - 1) * 100 with x = best-known tour length (>= optimum) "
                               "and x = Held-Karp 1-tree lower bound (<= optimum, subgradient ascent, oracle/one_tree.c)"}
         search_s = last.timing["search_s"]
-        n2 = (n - 2) * (n - 3) / 2.0
-        nr = float((n - 2) * (n - 2))
-        lds_bytes_per_eval = (48.0 * n2 + 68.0 * nr) / (n2 + nr)            # 48 B / 68 B per evaluation
         kern = kernel_rooflines(prof, n, min(chunk_eff, B), n_layers) if need_model else {}
         fwd_ms = sum(v["total_ms"] for v in kern.values())
         # dominant kernel of the timed step: the search kernel (by construction it runs for the whole budget).  One launch
-        # per round; algorithmic LDS bytes of a launch = evaluations of its instances x bytes per evaluation;
-        # duration from the HIP events recorded around the launch on its stream.  Rank 0's launches, last step's evaluations.
-        evals_rank0 = float(g[:B, 3].sum())
-        avg_launch_s = gls_ms / max(gls_launches, 1) * 1e-3
-        launches_per_step = max(int(gls_launches) // max(args.steps, 1), 1)
-        gls_gbs = evals_rank0 * lds_bytes_per_eval / launches_per_step / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # per round; duration from the HIP events recorded around the launch on its stream.  Rank 0's launches, last step's
+        # evaluation counts (reference-equivalent: evals_out; executed: the measurement hook).
         traffic = load_traffic().get("gls_kernel", {})
         resident = min(chunk_eff, B)
+        ratio = per_rank[0][3].item()
+        roof = search_roofline(n, args.steps, gls_ms, gls_launches, per_rank[0][4].item(), ratio if ratio >= 0 else None, resident, traffic,
+                               {"n": n, "instances": resident, "guide": "model" if args.guides == ["regret_pred"] else "+".join(args.guides)})
+        roof["device_time_share"] = gls_ms / (gls_ms + fwd_ms) if gls_ms + fwd_ms > 0 else None
+        # gap-versus-budget (test.py:97-117): all ranks' sums; the last point is the end of the budget
+        sums = sum(p[8:].cpu().numpy().reshape(-1, 3) for p in per_rank)
+        pre_search = sum(p[6].item() for p in per_rank) / max(total, 1)
+        curve = None
+        if not args.exact_gap and sums[0, 2] == total:
+            end_s = max(args.time_limit / (rounds if args.budget == "per_batch" and rounds else 1) - pre_search, 0.0)
+            curve = [p for p in gap_curve(sums, list(GAP_GRID_S) + [end_s], pre_search) if p["t_s"] < end_s or p["t_s"] == end_s]
+            if args.budget == "per_instance":                       # the end point IS the headline gap (same instances, same run)
+                assert abs(curve[-1]["mean_gap_pct"] - float(gap.mean())) <= 1e-9 * max(1.0, abs(float(gap.mean()))), "gap curve end point"
+        if grouped:
+            par = f"instance-sharded x{world}, one gather ({'RCCL' if backend == 'nccl' else backend}, world_size {dist.get_world_size()})"
+        else:
+            par = "instance-sharded x1, no process group (single rank: the gather is the identity)"
         out = {
             "metric": f"TSP instances/sec + mean opt-gap @{args.time_limit:g}s, TSP{n}", "value": value, "unit": "instances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -378,7 +599,14 @@ def main():
                        "n": n, "instances_per_gpu": B, "total_instances": total, "resident_instances_per_gpu": chunk,
                        "rounds_per_rank": [int(p[2].item()) for p in per_rank],
                        "time_limit_s": args.time_limit, "budget": args.budget, "perturbation_moves": args.perturbation_moves,
-                       "guides": args.guides, "parallelism": f"instance-sharded x{world}, one gather (RCCL)"},
+                       "guides": args.guides, "parallelism": par,
+                       "backend": (("RCCL (nccl)" if backend == "nccl" else backend) if grouped else None), "world_size": world,
+                       "device_of_rank": [int(p[7].item()) for p in per_rank], "visible_devices": n_dev,
+                       "collectives_per_step": {k: v / max(args.steps, 1) for k, v in collectives.items()} if grouped else {},
+                       # strong scaling: instances a rank searches / (rounds x device residency) -- configs[3] on 8 GPUs is
+                       # 1250 / (2 x 1024) = 0.61 by arithmetic ("10 s per instance" makes a partly filled round cost a full one)
+                       "residency_utilisation": [float(sz) / (max(int(p[2].item()), 1) * max(chunk, 1)) for sz, p in
+                                                 zip(sizes if sizes is not None else [B] * world, per_rank)]},
             "mean_gap_pct": float(gap.mean()) if gap is not None else None, "gap_reference": gap_reference,
             "true_gap_bracket_pct": [bracket["vs_best_known_pct"], bracket["vs_lower_bound_pct"]] if bracket else None,
             "true_gap_bracket": bracket,
@@ -390,26 +618,13 @@ def main():
             "watchdog_aborts": int((g[:, 4] == ops.STATUS_WATCHDOG).sum()),
             "penalty_overflows": int((g[:, 4] == ops.STATUS_PENALTY_OVERFLOW).sum()),
             "forward_s_per_step": last.timing["forward_s"], "search_s_per_step": search_s,
-            # the kernel that owns the timed step (98 % of device time): LDS-bound by design (HBM fraction ~0), see DESIGN.md
-            "roofline": {"kernel": "gls_kernel", "bound": "lds", "achieved": gls_gbs, "peak": PEAK_LDS_GBS, "unit": "GB/s",
-                         "frac": gls_gbs / PEAK_LDS_GBS,
-                         "traffic": traffic.get("hbm_bytes_per_instance_second", 0.0) * resident * avg_launch_s
-                         if "hbm_bytes_per_instance_second" in traffic else None,
-                         "delta_evals_per_s": evals_rank0 / launches_per_step / avg_launch_s if avg_launch_s > 0 else 0.0,
-                         "lds_bytes_per_eval": lds_bytes_per_eval, "avg_launch_ms": avg_launch_s * 1e3,
-                         "launches": int(gls_launches), "resident_instances": resident,
-                         "device_time_share": gls_ms / (gls_ms + fwd_ms) if gls_ms + fwd_ms > 0 else None,
-                         "pmc": {k: traffic[k] for k in ("valu_busy_frac", "lds_busy_frac", "lds_bank_conflict_frac", "wave_wait_frac",
-                                                         "hbm_gbs", "clock_ghz", "source") if k in traffic},
-                         # what the committed counters say binds the kernel (advisory; `bound`/`frac` above stay the algorithmic
-                         # LDS figure SURVEY 8(d) defines, which is what the rounds are compared on)
-                         "binding_resource": {"name": "valu_issue", "frac": traffic.get("valu_busy_frac"),
-                                              "second": "lds", "second_frac": traffic.get("lds_busy_frac")},
-                         "note": "LDS bytes are algorithmic (48 B per 2-opt, 68 B per relocate evaluation, SURVEY 8d).  The counters "
-                                 "(pmc, committed PMC passes on the same kernel) say what actually binds it at full residency: "
-                                 "vector-instruction issue first (VALU pipe %.0f %% busy), the LDS pipe second (%.0f %% busy), HBM ~1 %%.  "
-                                 % (100 * traffic.get("valu_busy_frac", float("nan")), 100 * traffic.get("lds_busy_frac", float("nan"))) +
-                                 "The forward kernels' MFMA / HBM rooflines are under `kernels`"},
+            # search-progress record of the SAME timed step (zero extra device time): mean gap / share of instances at the
+            # best-known length after t_s seconds of search (the budget clock of test.py:64 also counts the forward pass:
+            # budget_t_s); the last point is the end of the budget = mean_gap_pct
+            "gap_vs_budget": curve, "gap_vs_budget_note": None if curve else (curve_reason if bk_local is None else "incomplete"),
+            "pre_search_s": pre_search, "improvement_trace_truncated_instances": int(sum(p[5].item() for p in per_rank)),
+            # the kernel that owns the timed step (98 % of device time)
+            "roofline": roof,
             "gls_ms_per_rank": [p[0].item() for p in per_rank],
             "kernels": kern, "forward_kernels_ms_total": fwd_ms,
         }
@@ -422,6 +637,10 @@ def main():
             init_cost = ops.tour_cost(init, Ds)
             out["cpu_baseline"] = cpu_baseline(D_host[:cores], guides_host, init.cpu().numpy(), init_cost.cpu().numpy(),
                                                bk, args.time_limit, args.perturbation_moves, cores)
+            wb = out["cpu_baseline"]["whole_box_estimate"]
+            wb["gpu_over_whole_box"] = value / wb["instances_per_s"] if wb["instances_per_s"] > 0 else None
+        if world == 1 and not args.no_iso_quality and not strong and not args.exact_gap:
+            out["iso_quality"] = iso_quality_pass(args, n, resident, model, scalers, pipeline)
         print(json.dumps(out))
     if grouped:
         dist.barrier()

@@ -45,6 +45,7 @@ SIGNATURES = {
     "gnngls_gls_waves_per_simd": [_int, _int, _int],
     "gnngls_profile_enable": [_int],
     "gnngls_profile_collect": [_vp, _vp],
+    "gnngls_profile_set_executed_evals": [_vp],
 }
 
 PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine(unused)", "gemm_ffn1(unused)", "gemm_ffn2(unused)",

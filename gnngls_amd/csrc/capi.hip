@@ -60,6 +60,7 @@ int g_pen16_limit = 65535;
 std::atomic<int> g_prune_mode{-1};     // -1 / 1 = pruned descent scans where they exist, 0 = full scans (experiments / tests)
 std::atomic<int> g_team_mode{-1};      // -1 = policy (gls_config), 0 = never, 1 = wherever the team form exists (experiments / tests)
 long long *g_stamp_buffer = nullptr;
+std::atomic<long long *> g_exec_evals{nullptr};   // measurement hook (gnngls_profile_set_executed_evals)
 
 constexpr size_t kLdsPerCU = 160 * 1024;
 constexpr int kMaxWavesPerCU = 32;
@@ -77,15 +78,15 @@ int num_cus() {
 // most resident workgroups per CU wins; ties go to the faster store (LDS penalties, 32-bit first).
 struct GlsConfig { int store; int penalty_bits; int threads; size_t lds; int per_cu; int wps; bool team = false; bool prune = false; };
 
-GlsConfig gls_config_store(int n, int requested_bits, int batch);
+GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_improvement);
 
 // + the form of the perturbation phase: on all wavefronts of the workgroup (team) when every workgroup of the batch gets a
 // CU of its own (B <= number of CUs) and is a 16-wave workgroup (TSP200 x 256: one per CU by LDS anyway) -- else on
 // wavefront 0
-GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
-    GlsConfig c = gls_config_store(n, requested_bits, batch);
+GlsConfig gls_config(int n, int requested_bits, int batch = 0, bool first_improvement = false) {
+    GlsConfig c = gls_config_store(n, requested_bits, batch, first_improvement);
     const int mode = g_team_mode.load(std::memory_order_relaxed);
-    if (mode != 0 && gnngls::gls_team_supported(c.store, c.penalty_bits, c.wps, n)) {
+    if (mode != 0 && gnngls::gls_team_supported(c.store, c.penalty_bits, c.wps, n, c.threads)) {
         const size_t lds = gnngls::gls_lds_bytes(n, c.store, c.penalty_bits, true);
         // ... and only for the 16-wave workgroups that own a CU by their LDS footprint (distance triangle > 80 KB: n >= 144,
         // TSP200).  Measured (outer iterations in 2 s, team vs serial): TSP200 x 256 13.0k vs 10.9k (weight guide), 10.5k vs
@@ -101,12 +102,12 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0) {
 // + the pruned descent scans (nearest-neighbour lists: 2-opt scan from n = 80, relocate scan from n = 128; the position table
 // sits in the LDS slot the best tour used to have, so the footprint does not change)
 GlsConfig gls_config_run(int n, int requested_bits, int batch, bool first_improvement) {
-    GlsConfig c = gls_config(n, requested_bits, batch);
+    GlsConfig c = gls_config(n, requested_bits, batch, first_improvement);
     c.prune = g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement);
     return c;
 }
 
-GlsConfig gls_config_store(int n, int requested_bits, int batch) {
+GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_improvement) {
     GlsConfig pick{gnngls::GLS_STORE_GLOBAL, 32, gnngls::gls_block_threads(n, gnngls::GLS_STORE_GLOBAL),
                    gnngls::gls_lds_bytes(n, gnngls::GLS_STORE_GLOBAL, 32), 0, 4};
     bool have = false, done = false;
@@ -117,7 +118,8 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch) {
         if (done) return;
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
         if (lds > kLdsPerCU) return;
-        int threads = gnngls::gls_block_threads(n, store, bits);
+        // single-wavefront workgroups for n <= 33 only where the half-wave descent scans exist: best improvement, 128-VGPR build
+        int threads = gnngls::gls_block_threads(n, store, bits, !first_improvement);
         // compact store, batch larger than the 128-VGPR build keeps resident at the default workgroup size: halve the
         // workgroup (down to the wavefronts the lean scans need, one per block of 64 rows) before falling back to the
         // 64-VGPR build -- TSP50 x 2048 on 2-wave workgroups at 128 VGPRs: 6.2k outer iterations per second vs 5.6k on
@@ -137,6 +139,10 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch) {
         int wps = gnngls::gls_waves_per_simd(store, n, batch, cus, threads, lds);
         if (store == gnngls::GLS_STORE_COMPACT && batch <= 0) wps = 8;
         if (store == gnngls::GLS_STORE_TRI && bits == 16) wps = 6;            // the uint16 variant only exists as the 80-VGPR build
+        // (n = 25..33 beyond the 128-VGPR residency end up on the 64-VGPR build, which has no half-wave scans, still as ONE
+        // wavefront per instance: measured TSP30 x 8192, 1 s -- 64 threads keep all 8192 resident, 6.2k iterations each;
+        // 128 threads halve the residency: 8.8k iterations each in two rounds of 1 s, half the aggregate rate
+        // (profiles/r04_ab_threads_tsp30x8192.log))
         const int by_waves = (wps * 4) / (threads / 64);
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;
@@ -265,6 +271,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     A.pen16_limit = g_pen16_limit;
     A.imp_cost = imp_cost; A.imp_time = imp_time; A.imp_iter = (long long *)imp_iter; A.imp_cap = imp_cap; A.imp_len = imp_len;
     A.stamps = g_stamp_buffer;
+    A.evals_exec = g_exec_evals.load(std::memory_order_relaxed);
     A.trace_len = trace_len; A.penalty_out = penalty_out; A.evals = (long long *)evals_out; A.status = status;
     const GlsConfig cfg = gls_config_run(n, penalty_bits, B, first_improvement != 0);
     if (cfg.lds > kLdsPerCU)     // even the global-memory store keeps tours and per-position edge lengths in LDS
@@ -284,6 +291,13 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
         A.pen_ws = ws;
     }
     hipError_t e;
+    if (A.evals_exec) {          // the wavefronts of an instance add their counts atomically
+        // a run that prunes on an instantiation without the counting code cannot report the executed evaluations: -1
+        const bool unknown = cfg.prune && !gnngls::gls_count_supported(cfg.store, cfg.wps, n, first_improvement != 0, A.trace_cap > 0);
+        e = hipMemsetAsync(A.evals_exec, unknown ? 0xff : 0, (size_t)B * sizeof(long long), st);
+        if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: executed-evaluations buffer"); }
+        if (unknown) A.evals_exec = nullptr;
+    }
     void *nl = nullptr;          // nearest-neighbour lists of the pruned descent scans
     if (cfg.prune) {
         const size_t entries = (size_t)B * n * gnngls::kNeighborListLen;
@@ -638,6 +652,11 @@ extern "C" {
 int gnngls_debug_set_penalty16_limit(int limit) {
     if (limit < 1 || limit > 65535) return fail(GNNGLS_ERR_ARG, "penalty16 limit must be in 1..65535");
     g_pen16_limit = limit;
+    return GNNGLS_OK;
+}
+
+int gnngls_profile_set_executed_evals(int64_t *device_buffer) {
+    g_exec_evals.store((long long *)device_buffer, std::memory_order_relaxed);
     return GNNGLS_OK;
 }
 

@@ -26,6 +26,8 @@ struct GlsArgs {
     int32_t *trace_len;
     int32_t *penalty_out;
     long long *evals;
+    long long *evals_exec;     // [B] or NULL: evaluations actually executed (the counting instantiations book the pruned scans'
+                               // candidates; the others copy `evals`), zeroed by the host
     int32_t *status;
     int32_t *pen_ws;           // global store: [B,n,n] int32; compact store: [B,n(n-1)/2] int32; zeroed by the host
     int pen16_limit;           // 65535 (see gnngls_debug_set_penalty16_limit)
@@ -44,18 +46,19 @@ struct GlsArgs {
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
 size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team = false);
-int gls_block_threads(int n, int store, int penalty_bits = 32);
+int gls_block_threads(int n, int store, int penalty_bits = 32, bool half_scans = true);
 void gls_set_block_threads_override(int threads);   // 0 = default policy (experiments only)
 // resident wavefronts per SIMD (= register budget) of the kernel instantiation for this configuration: 4 or 8 for the
 // compact store, fixed for the others
 int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, size_t lds);
 // team: perturbation phase on all wavefronts of the workgroup (for workgroups that own their CU); only where
 // gls_team_supported() says so
-bool gls_team_supported(int store, int penalty_bits, int wps, int n);
+bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads);
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
 constexpr int kNeighborListLen = 32;
 bool gls_prune_supported(int store, int n, bool first_improvement);
+bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool trace);
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,

@@ -60,6 +60,9 @@ namespace gnngls {
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
 #endif
+#ifndef GLS_SKIP_DEAD_PASS
+#define GLS_SKIP_DEAD_PASS 1         // pruned descent scans: a wavefront without rows in a pass skips it
+#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
 #endif
@@ -1053,10 +1056,15 @@ struct NlWords {
 };
 constexpr int kPruneMinNodes = 80;       // 2-opt scan pruned from here up (same-box A/B at n = 66 .. 127), relocate from n = 128
 
-template <class S, class TT>
+template <bool CNT, class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
                                                         const NlWords &nlw, int n,
-                                                        int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
+                                                        int tid, int nthr, int lane, double &bd, int &bk, int &xe,
+                                                        long long *dbg = nullptr) {
+    // CNT (the counting instantiations, GlsArgs::evals_exec): xe (wave-uniform, scalar registers) += delta evaluations this
+    // wavefront executes -- candidates under the exec mask, whole rows on overflow.  Measured cost of counting: 1.8-3.2 % of the
+    // outer iterations (profiles/r04_ab_exec_counter.log), hence instantiations of their own that only bench.py's counting
+    // pass launches
     const PlainDist<S> f{s};
     const int tasks = 8 * (n - 1);                           // 8 lanes per tour row, two list entries per lane and level
     const int rowbit = (lane & 56) + 7;                      // lane that holds entries 15 / 31 of this lane's row
@@ -1064,6 +1072,11 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
     for (int task0 = 0; task0 < tasks; task0 += nthr, ++it) {      // wave-uniform trip count; a wavefront's tasks are whole rows
         const int task = task0 + tid;
         const bool live = task < tasks;
+#if GLS_SKIP_DEAD_PASS
+        // a wavefront none of whose lanes has a row in this pass (n = 100: 792 tasks on 256 threads -- the fourth pass only
+        // has rows for wavefront 0) leaves the scan here: later passes have none for it either
+        if (__builtin_amdgcn_readfirstlane(task0 + (tid & ~(kWave - 1))) >= tasks) break;
+#endif
         // the row of NODE x (every node but the depot has one), wherever it sits in the tour: p = pos[x]
         const int x = 1 + (live ? task >> 3 : 0), m = task & 7;
         const unsigned ids4 = nlw.of(it);
@@ -1086,6 +1099,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
                 // y = t[q]: (a, c) = (x, y) of the move (i, j) = (p, q) if q >= p + 2; (d, b) = (x, y) of (q + 1, p + 1) if q <= p - 2
                 const bool ca = act && d < ep && q >= p + 2;
                 const bool cb = act && d < es && q <= p - 2 && p <= n - 2;
+                if constexpr (CNT) xe += __popcll(__ballot(ca || cb));
                 if (ca || cb) {
                     const int o2 = t[ca ? q - 1 : q + 1];
                     const double e2 = Ef[ca ? q : q + 1];
@@ -1110,6 +1124,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
             const int src = __ffsll((long long)om) - 1;
             om &= om - 1;
             const int pr = __builtin_amdgcn_readlane(p, src);
+            if constexpr (CNT) xe += (n - 2 - pr > 0 ? n - 2 - pr : 0) + (pr + 1 <= n - 1 ? pr - 1 : 0);
             for (int j = pr + 2 + lane; j <= n - 1; j += kWave) consider<false>(two_opt_cost(t, f, pr, j), make_key(pr, j), bd, bk);
             if (pr + 1 <= n - 1)
                 for (int i = 1 + lane; i <= pr - 1; i += kWave) consider<false>(two_opt_cost(t, f, i, pr + 1), make_key(i, pr + 1), bd, bk);
@@ -1117,11 +1132,12 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
     }
 }
 
-template <class S, class TT>
+template <bool CNT, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
                                                          const NlWords &nlw, int n, double Lcap,
                                                          const int *longk, int nlong,
-                                                         int tid, int nthr, int lane, double &bd, int &bk, long long *dbg = nullptr) {
+                                                         int tid, int nthr, int lane, double &bd, int &bk, int &xe,
+                                                         long long *dbg = nullptr) {
     const PlainDist<S> f{s};
     const int tasks = 8 * (n - 1);
     const int rowbit = (lane & 56) + 7;
@@ -1129,6 +1145,9 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
     for (int task0 = 0; task0 < tasks; task0 += nthr, ++it) {
         const int task = task0 + tid;
         const bool live = task < tasks;
+#if GLS_SKIP_DEAD_PASS
+        if (__builtin_amdgcn_readfirstlane(task0 + (tid & ~(kWave - 1))) >= tasks) break;      // see scan_two_opt_a2a_pruned
+#endif
         const int b = 1 + (live ? task >> 3 : 0), m = task & 7;      // the row of NODE b, at tour position p
         const unsigned ids4 = nlw.of(it);
         const int p = pos[b];
@@ -1142,14 +1161,15 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
         const double Tmax = Lcap - base;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (live && m + 8 * u < nlong) {
-                const int k = longk[m + 8 * u];
-                if ((unsigned)(k - p + 2) > 2u) {
-                    double delta = base - Ef[k + 1];             // operators.py:100-102, left to right
-                    delta = delta + s.dist(t[k], b);             // +D[d,b]
-                    delta = delta + s.dist(b, t[k + 1]);         // +D[b,e]
-                    consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
-                }
+            const bool lk = live && m + 8 * u < nlong;
+            const int k = lk ? longk[m + 8 * u] : p;             // (k = p is never a valid target)
+            const bool ev = (unsigned)(k - p + 2) > 2u;
+            if constexpr (CNT) xe += __popcll(__ballot(ev));
+            if (ev) {
+                double delta = base - Ef[k + 1];                 // operators.py:100-102, left to right
+                delta = delta + s.dist(t[k], b);                 // +D[d,b]
+                delta = delta + s.dist(b, t[k + 1]);             // +D[b,e]
+                consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
             }
         }
         bool more = live;
@@ -1171,6 +1191,7 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
                 // valid targets of row p: k not in {p-2, p-1, p} (operators.py:133-136: i - j == 1 <=> k = p - 2)
                 const bool c1 = act && (unsigned)(k1 - p + 2) > 2u && two_d < e1 - base;
                 const bool c2 = act && (unsigned)(k2 - p + 2) > 2u && two_d < e2 - base;
+                if constexpr (CNT) xe += __popcll(__ballot(c1)) + __popcll(__ballot(c2));
                 if (c1) {
                     double delta = base - e1;                    // operators.py:100-102, left to right
                     delta = delta + d;                           // +D[d,b]
@@ -1197,6 +1218,7 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
             const int src = __ffsll((long long)om) - 1;
             om &= om - 1;
             const int pr = __builtin_amdgcn_readlane(p, src);
+            if constexpr (CNT) xe += n - 2 - (pr > 1 ? 1 : 0);
             for (int j = 1 + lane; j <= n - 1; j += kWave) {
                 if (j == pr || pr - j == 1) continue;
                 consider<false>(relocate_cost(t, f, pr, j), make_key(pr, j), bd, bk);
@@ -1233,7 +1255,9 @@ __global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, in
             double best = __builtin_inf(); int by = -1;
             for (int y = 0; y < n; ++y) {
                 if (y == x) continue;
-                const double v = row[y];
+                // the element of the LOWER triangle, D[max, min] -- the one the search kernel keeps in LDS and compares the
+                // lists against: the order of a list is then exact for that image even if D is asymmetric by a few ulps
+                const double v = y < x ? row[y] : Dg[(size_t)y * n + x];
                 if (m == 0 && !(fabs(v) <= 1e6)) bad = 1;        // also catches NaN / inf
                 if ((v > last_d || (v == last_d && y > last_y)) && (by < 0 || v < best)) { best = v; by = y; }
             }
@@ -1643,12 +1667,13 @@ struct PruneCtx {
     NlWords nlw; bool on;
 };
 
-template <class S, bool FI, int GP, class TT, class TRC>
+template <class S, bool FI, int GP, bool CNT, class TT, class TRC>
 __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
-                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, Stamps &st,
+                                 Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, long long &xe, Stamps &st,
                                  TT *ppos, const PruneCtx &pc) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // pruned descent scans (given neighbour lists): the 2-opt scan from n = 80 up, the relocate scan from n = 128 up (the
     // 4-slot instantiations) -- where each was measured faster (profiles/r03_experiments/README.md)
     constexpr bool kCanPrune = !FI && S::kSymmetric;
@@ -1697,7 +1722,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
-            bool lean = false;
+            bool lean = false, pruned_scan = false;
+            int xs = 0;          // evaluations this wavefront executes in a pruned scan (scalar; booked once per scan below)
             if constexpr (kCanPrune) {
                 int nlong = 0;
                 if (kPruneRelocate && prune && op == 1) {
@@ -1721,10 +1747,10 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 #else
                     long long *dbg = nullptr;
 #endif
-                    if (op == 0) scan_two_opt_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.nlw, n, tid, nthr, lane, bd, bk, dbg);
+                    if (op == 0) scan_two_opt_a2a_pruned<CNT, S, TT>(s, t, ppos, Ef, pc.nlw, n, tid, nthr, lane, bd, bk, xs, dbg);
                     else if constexpr (kPruneRelocate)
-                        scan_relocate_a2a_pruned<S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, dbg);
-                    lean = true;
+                        scan_relocate_a2a_pruned<CNT, S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, xs, dbg);
+                    lean = true; pruned_scan = true;
                 }
             }
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
@@ -1761,6 +1787,10 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             STAMP_END(9);    // wave + workgroup arg-min (includes waiting for the slowest wave)
             STAMP_COUNT(11);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
+            // executed count = evals + sum over the wavefronts of xe: a pruned scan booked the candidates it evaluated, and
+            // wavefront 0 takes the scan's reference count back (uniform branch: xe stays in scalar registers)
+            if (CNT && pruned_scan)
+                xe += xs - (wave_u == 0 ? ((op == 0) ? (n - 2) * (n - 3) / 2 : (n - 2) * (n - 2)) : 0);
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
@@ -1781,7 +1811,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 // exists twice: WPS 4 (128 VGPRs, no spills: the instantiation a full TSP100 device load runs on, four 4-wave workgroups
 // per CU) and WPS 8 (64 VGPRs, ~100 B of scratch) for batches of small instances that need more than 16 waves per CU.
 // TEAM: the perturbation phase runs on all wavefronts (team_perturbation above) -- for workgroups that own their CU.
-template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM = false>
+// CNT: also count the delta evaluations the pruned descent scans execute (GlsArgs::evals_exec; measurement builds, see there).
+template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM = false, bool CNT = false>
 __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
@@ -1887,7 +1918,8 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             pc.on = true;
         }
     }
-    local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);   // algorithms.py:142
+    long long xe = 0;        // executed minus reference-equivalent evaluations of this wavefront's pruned scans (CNT builds)
+    local_search_dev<S, FI, GP, CNT>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
@@ -2042,7 +2074,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI, GP>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, st, ppos, pc);
+        local_search_dev<S, FI, GP, CNT>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -2066,6 +2098,15 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             if (A.imp_iter) A.imp_iter[q] = iter_i;
         }
         A.imp_len[b] = l + 1;
+    }
+    if constexpr (CNT) {
+        // executed evaluations = evals (thread 0: everything the reference evaluates) + every wavefront's xe (candidates of
+        // the pruned scans minus those scans' reference counts).  Zeroed by the host.
+        if (A.evals_exec && lane == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(A.evals_exec + b), (unsigned long long)(xe + (tid == 0 ? evals : 0ll)));
+    } else if (A.evals_exec && tid == 0) {
+        // the host only hands this instantiation the buffer when no scan of the run is pruned: executed = reference count
+        A.evals_exec[b] = evals;
     }
     if (tid == 0) {
         A.best_cost[b] = best_cost;
@@ -2219,14 +2260,16 @@ size_t gls_lds_bytes(int n, int store, int penalty_bits, bool team) {
 static std::atomic<int> g_threads_override{0};      // experiments only (gnngls_debug_set_gls_threads)
 void gls_set_block_threads_override(int threads) { g_threads_override.store(threads, std::memory_order_relaxed); }
 
-int gls_block_threads(int n, int store, int penalty_bits) {
+int gls_block_threads(int n, int store, int penalty_bits, bool half_scans) {
     const int forced = g_threads_override.load(std::memory_order_relaxed);
     if (forced > 0) return forced;
     if (n <= 24) return 64;
     // n <= 33 on the stores that have the half-wave descent scans: ONE wavefront using both its 32-lane halves beats two
     // wavefronts sharing the lean scans (outer iterations in 2 s, x 1000, noise guide: n = 26 24.2k -> 25.7k, n = 30 22.6k ->
     // 24.1k, n = 33 21.1k -> 22.4k)
-    if (GLS_HALF_SCANS && n <= kHalfScanMaxNodes && penalty_bits == 32 && (store == GLS_STORE_COMPACT || store == GLS_STORE_TRI))
+    // (half_scans = false: the caller knows the launch ends up on an instantiation without them -- first improvement, or the
+    // 64- / 80-VGPR builds -- where one wavefront would run the two-wavefront scans alone)
+    if (GLS_HALF_SCANS && half_scans && n <= kHalfScanMaxNodes && penalty_bits == 32 && (store == GLS_STORE_COMPACT || store == GLS_STORE_TRI))
         return 64;
     if (n <= 48) return 128;
     if (n <= 80) return 256;
@@ -2263,9 +2306,9 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
     return (batch > 0 && (long)per_cu4 * num_cus < batch && 32 / waves > per_cu4 && by_lds > per_cu4) ? 8 : 4;
 }
 
-template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM>
+template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM, bool CNT = false>
 static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
-    auto kern = gls_kernel<S, FI, GP, TR, WPS, TEAM>;
+    auto kern = gls_kernel<S, FI, GP, TR, WPS, TEAM, CNT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2276,6 +2319,11 @@ static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStr
 
 template <class S, bool FI, int GP, int WPS, bool TEAM>
 static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
+    // counting instantiations (executed evaluations of the pruned scans): compact store, best improvement, 128-VGPR build,
+    // no per-move trace -- gls_count_supported() says the same to the host
+    if constexpr (!FI && WPS == 4 && GP >= 2 && std::is_base_of<TriDGlobalP, S>::value) {
+        if (A.evals_exec && A.nl_id && !(A.trace_cap > 0 && A.trace_cost)) return launch_gls_k<S, FI, GP, false, WPS, TEAM, true>(A, lds, threads, stream);
+    }
     // trace_cap == 0 (no trace buffer): the trace-free instantiation (fewer live registers in the serial phase)
     if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true, WPS, TEAM>(A, lds, threads, stream);
     return launch_gls_k<S, FI, GP, false, WPS, TEAM>(A, lds, threads, stream);
@@ -2301,14 +2349,16 @@ static hipError_t launch_gls_f(const GlsArgs &A, size_t lds, int threads, bool f
                              : launch_gls_t<S, false, WPS, TEAM>(A, lds, threads, stream);
 }
 
-bool gls_team_supported(int store, int penalty_bits, int wps, int n) {
-    // the team form exists for the 128-VGPR builds of the two symmetric stores with 32-bit counters, n <= 255
-    return (store == GLS_STORE_COMPACT || (store == GLS_STORE_TRI && penalty_bits == 32)) && wps == 4 && n >= 4 && n <= 255;
+bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads) {
+    // the team form exists for the 128-VGPR builds of the two symmetric stores with 32-bit counters, n <= 255; it caches the
+    // utilities of the tour edges by position on wavefronts 0 .. ceil(n / 64) - 1, so the workgroup needs that many
+    return (store == GLS_STORE_COMPACT || (store == GLS_STORE_TRI && penalty_bits == 32)) && wps == 4 && n >= 4 && n <= 255 &&
+           threads / kWave >= (n + kWave - 1) / kWave;
 }
 
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream) {
-    if (team && !gls_team_supported(store, penalty_bits, wps, A.n)) return hipErrorInvalidValue;
+    if (team && !gls_team_supported(store, penalty_bits, wps, A.n, threads)) return hipErrorInvalidValue;
     size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
     if (store == GLS_STORE_COMPACT) {
         if (team) return launch_gls_f<TriDGlobalPF, 4, true>(A, lds, threads, first_improvement, stream);
@@ -2323,6 +2373,13 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                         : launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     }
     return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+}
+
+// executed-evaluation counting (measurement hook) exists where gls_count_supported says; elsewhere a run that prunes cannot
+// report it
+bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool trace) {
+    (void)n;
+    return store == GLS_STORE_COMPACT && wps == 4 && !first_improvement && !trace;
 }
 
 // pruned descent scans exist in the 4-slot instantiations of the symmetric stores (n >= 128), best improvement only; the

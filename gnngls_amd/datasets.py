@@ -26,10 +26,18 @@ def is_lfs_pointer(path):
 
 
 def read_gpickle(path):
+    """nx.read_gpickle (datasets.py:56,69; gone in networkx 3) = pickle.load.  The reference's files were written by
+    networkx 2.8 (Pipfile.lock): such a Graph unpickles under networkx 3.x with the views its generating code touched
+    (`nodes`, `edges`, `adj`, `degree`: cached properties) in the instance dict and without the `__networkx_cache__` slot
+    3.x creates in `Graph.__init__`; the slot is added here so the object is a complete 3.x graph (fixture:
+    tests/golden/n3_tsp12/, tests/test_n3_ingestion_cpu.py)."""
     if is_lfs_pointer(path):
         raise FileNotFoundError(f"{path} is a git-LFS pointer stub, not the real object (fetch it with git lfs pull)")
     with open(path, "rb") as f:
-        return pickle.load(f)
+        obj = pickle.load(f)
+    if hasattr(obj, "_adj") and hasattr(obj, "_node") and "__networkx_cache__" not in getattr(obj, "__dict__", {}):
+        obj.__dict__["__networkx_cache__"] = {}
+    return obj
 
 
 def set_features(G):

@@ -215,6 +215,25 @@ class gls_prune_mode:
         return False
 
 
+class executed_evals:
+    """Measurement hook (gnngls_profile_set_executed_evals): `with executed_evals(B_max) as x: gls_run(...)` -> x.counts
+    [B_max] int64 holds, for the LAST gls_run launch inside the block, the delta evaluations the kernel actually executed
+    per instance (<= GlsResult.evals, which counts what the reference evaluates; equal where no scan is pruned; -1 where
+    the run pruned on a configuration without the counting instantiations -- see include/gnngls_hip.h).  A launch inside
+    the block runs the COUNTING instantiation of the kernel (2-3 % slower): measure speed outside of it."""
+
+    def __init__(self, capacity):
+        self.counts = torch.zeros((int(capacity),), dtype=torch.int64, device=_dev())
+
+    def __enter__(self):
+        _lib.check(_lib.load().gnngls_profile_set_executed_evals(_lib.ptr(self.counts)), "profile_set_executed_evals")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.load().gnngls_profile_set_executed_evals(None), "profile_set_executed_evals")
+        return False
+
+
 def gls_describe_config(n, B=0, penalty_bits=0):
     """-> dict(store, threads, lds_bytes, per_cu, team, waves_per_simd): what gnngls_gls_run would use (host-side query)."""
     vals = [ctypes.c_int(0) for _ in range(4)]

@@ -64,6 +64,7 @@ class SolveResult:
     imp_time: torch.Tensor = None
     imp_iter: torch.Tensor = None
     imp_len: torch.Tensor = None
+    evals_executed: torch.Tensor = None   # [B] int64, only with count_executed (measurement hook, ops.executed_evals)
     start_time: torch.Tensor = None    # [B] fp64 host time.time() at which the instance's budget started (test.py:64)
     launch_time: torch.Tensor = None   # [B] fp64 host time.time() just before its search kernel was launched
 
@@ -86,14 +87,15 @@ def predict_regret(model, D, scalers, features=None):
 
 def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit=10.0, perturbation_moves=20,
                 first_improvement=False, max_outer_iters=-1, trace_cap=0, want_trace_time=False, chunk=None,
-                keep_regret=False, budget="per_instance", imp_cap=0, features=None):
+                keep_regret=False, budget="per_instance", imp_cap=0, features=None, count_executed=False):
     """D [B,n,n] fp64 CUDA tensor (symmetric).  Returns SolveResult with per-instance tensors.
 
     budget="per_instance" (default, the reference's meaning of --time_limit, test.py:64,92): every instance is searched
     for `time_limit` seconds; a batch larger than the device capacity takes ceil(B/capacity) rounds of `time_limit` each.
     budget="per_batch": the whole batch finishes within `time_limit`; the rounds share it equally (each instance is
     searched for time_limit / rounds) -- the throughput end of the same trade, with the gap there to judge it.
-    features: see predict_regret (None = scaled edge weights packed on the device)."""
+    features: see predict_regret (None = scaled edge weights packed on the device).
+    count_executed: also return the delta evaluations the search kernel actually executed (bench.py's roofline)."""
     if budget not in ("per_instance", "per_batch"):
         raise ValueError(f"unknown budget policy {budget!r}")
     assert D.is_cuda and D.dtype == torch.float64
@@ -138,9 +140,16 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         torch.cuda.synchronize()
         t2 = time.time()
         remaining = max(round_limit - (t2 - t0), 0.0)
-        r = ops.gls_run(Dc, gt, init, init_cost, perturbation_moves=perturbation_moves,
-                        first_improvement=first_improvement, max_outer_iters=max_outer_iters,
-                        time_limit_s=remaining, trace_cap=trace_cap, want_trace_time=want_trace_time, imp_cap=imp_cap)
+        run = lambda: ops.gls_run(Dc, gt, init, init_cost, perturbation_moves=perturbation_moves,   # noqa: E731
+                                  first_improvement=first_improvement, max_outer_iters=max_outer_iters,
+                                  time_limit_s=remaining, trace_cap=trace_cap, want_trace_time=want_trace_time, imp_cap=imp_cap)
+        executed = None
+        if count_executed:
+            with ops.executed_evals(Dc.shape[0]) as x:
+                r = run()
+            executed = x.counts
+        else:
+            r = run()
         torch.cuda.synchronize()
         t3 = time.time()
         aborted = int((r.status == ops.STATUS_WATCHDOG).sum())
@@ -152,7 +161,8 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         timing["search_s"] += t3 - t2
         timing["chunks"] += 1
         outs.append((r, init_cost, R if keep_regret else None,
-                     torch.full((Dc.shape[0],), t0, dtype=torch.float64), torch.full((Dc.shape[0],), t2, dtype=torch.float64)))
+                     torch.full((Dc.shape[0],), t0, dtype=torch.float64), torch.full((Dc.shape[0],), t2, dtype=torch.float64),
+                     executed))
     cat = lambda xs: torch.cat(xs) if len(xs) > 1 else xs[0]  # noqa: E731
     return SolveResult(
         best_tour=cat([o[0].best_tour for o in outs]), best_cost=cat([o[0].best_cost for o in outs]),
@@ -166,6 +176,7 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
         imp_time=cat([o[0].imp_time for o in outs]) if imp_cap > 0 else None,
         imp_iter=cat([o[0].imp_iter for o in outs]) if imp_cap > 0 else None,
         imp_len=cat([o[0].imp_len for o in outs]) if imp_cap > 0 else None,
+        evals_executed=cat([o[5] for o in outs]) if count_executed else None,
         start_time=cat([o[3] for o in outs]), launch_time=cat([o[4] for o in outs]))
 
 

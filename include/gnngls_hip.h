@@ -236,6 +236,17 @@ enum {
 int gnngls_profile_enable(int on);
 int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);
 
+/* Measurement hook (bench.py): while a device buffer is set (NULL = off, the default), every gnngls_gls_run launch fills its
+ * first B int64 entries with the number of delta evaluations the kernel actually EXECUTED per instance.
+ * evals_out of gnngls_gls_run counts what the reference evaluates (operators.py:36-39,133-136: every move of every scan);
+ * the pruned descent scans (n >= 80) evaluate only the moves that can qualify, the full scans and the one-to-all scans of
+ * the perturbation phase every move once -- so executed <= evals_out, equal where nothing is pruned.  Counting costs the
+ * pruned scans 2-3 % (profiles/r04_ab_exec_counter.log), so it lives in kernel instantiations of their own that ONLY a
+ * launch with this hook set selects: compact store (penalty_bits 0 / -2 where that store is picked), best improvement, no
+ * per-move trace.  A pruning run on any other configuration reports -1 per instance.  The buffer must hold the largest B
+ * launched while it is set; process-wide, not per stream. */
+int gnngls_profile_set_executed_evals(int64_t *device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

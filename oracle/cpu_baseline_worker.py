@@ -24,4 +24,6 @@ r = go.guided_local_search(D, guides, init_tour, init_cost,
                            perturbation_moves=pm, max_outer_iters=-1, time_limit_s=time_limit, trace_cap=1,
                            want_penalty=False)
 print(json.dumps({"best_cost": r["best_cost"], "outer_iters": r["outer_iters"], "evals": r["evals"],
-                  "moves": r["trace_len"], "search_s": time.time() - t0}))
+                  "moves": r["trace_len"], "search_s": time.time() - t0,
+                  # search-progress record (the returned best at every improvement + the terminal entry, test.py:97-117)
+                  "imp_cost": r["imp_cost"].tolist(), "imp_time": r["imp_time"].tolist(), "imp_len": r["imp_len"]}))

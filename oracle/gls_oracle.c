@@ -237,14 +237,14 @@ static double now_s(void) {
  *            terminal entry (best_cost, outer iterations completed); *imp_len counts all of them
  * Returns best_cost.
  */
-double gls_oracle_guided_local_search(const double *D, const double *guides, int n_guides, int n,
+static double gls_impl(const double *D, const double *guides, int n_guides, int n,
                                       int32_t *tour, double init_cost,
                                       int perturbation_moves, int first_improvement,
                                       int64_t max_outer_iters, double time_limit_s,
                                       double *trace_cost, int trace_cap, int *trace_len,
                                       int32_t *penalty_out, int64_t *outer_iters_out,
                                       int64_t *evals_out,
-                                      double *imp_cost, int64_t *imp_iter, int imp_cap, int *imp_len) {
+                                      double *imp_cost, int64_t *imp_iter, int imp_cap, int *imp_len, double *imp_time) {
     double t0 = now_s();
     size_t nn = (size_t)n * (size_t)n;
     double k = 0.1 * init_cost / (double)n;                      /* :137 (left to right) */
@@ -261,7 +261,7 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     double best_cost = cur_cost;                                  /* :143 */
     memcpy(tour, cur, (size_t)(n + 1) * sizeof(int32_t));
     int n_imp = 0;
-    if (imp_cost && n_imp < imp_cap) { imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = 0; }
+    if (imp_cost && n_imp < imp_cap) { imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = 0; if (imp_time) imp_time[n_imp] = now_s() - t0; }
     n_imp++;
 
     int64_t iter_i = 0;
@@ -311,7 +311,9 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
         if (cur_cost < best_cost) {                               /* :190-191 */
             best_cost = cur_cost;
             memcpy(tour, cur, (size_t)(n + 1) * sizeof(int32_t));
-            if (imp_cost && n_imp < imp_cap) { imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = iter_i + 1; }
+            if (imp_cost && n_imp < imp_cap) {
+                imp_cost[n_imp] = best_cost; if (imp_iter) imp_iter[n_imp] = iter_i + 1; if (imp_time) imp_time[n_imp] = now_s() - t0;
+            }
             n_imp++;
         }
         iter_i++;
@@ -322,12 +324,40 @@ double gls_oracle_guided_local_search(const double *D, const double *guides, int
     if (evals_out) *evals_out = evals;
     if (imp_cost && imp_cap > 0) {                                /* terminal entry: returned best, completed iterations */
         int q = n_imp < imp_cap ? n_imp : imp_cap - 1;
-        imp_cost[q] = best_cost; if (imp_iter) imp_iter[q] = iter_i;
+        imp_cost[q] = best_cost; if (imp_iter) imp_iter[q] = iter_i; if (imp_time) imp_time[q] = now_s() - t0;
     }
     n_imp++;
     if (imp_len) *imp_len = n_imp;
     free(pen); free(Dg); free(cur);
     return best_cost;
+}
+
+double gls_oracle_guided_local_search(const double *D, const double *guides, int n_guides, int n,
+                                      int32_t *tour, double init_cost,
+                                      int perturbation_moves, int first_improvement,
+                                      int64_t max_outer_iters, double time_limit_s,
+                                      double *trace_cost, int trace_cap, int *trace_len,
+                                      int32_t *penalty_out, int64_t *outer_iters_out,
+                                      int64_t *evals_out,
+                                      double *imp_cost, int64_t *imp_iter, int imp_cap, int *imp_len) {
+    return gls_impl(D, guides, n_guides, n, tour, init_cost, perturbation_moves, first_improvement, max_outer_iters,
+                    time_limit_s, trace_cost, trace_cap, trace_len, penalty_out, outer_iters_out, evals_out,
+                    imp_cost, imp_iter, imp_cap, imp_len, NULL);
+}
+
+/* The same search with the wall-clock time (seconds since the call started) of every improvement-trace entry in imp_time
+ * [imp_cap] -- bench.py's cpu_baseline leg reports the CPU's gap-versus-budget curve from it (test.py:97-117). */
+double gls_oracle_guided_local_search_timed(const double *D, const double *guides, int n_guides, int n,
+                                            int32_t *tour, double init_cost,
+                                            int perturbation_moves, int first_improvement,
+                                            int64_t max_outer_iters, double time_limit_s,
+                                            double *trace_cost, int trace_cap, int *trace_len,
+                                            int32_t *penalty_out, int64_t *outer_iters_out,
+                                            int64_t *evals_out,
+                                            double *imp_cost, int64_t *imp_iter, int imp_cap, int *imp_len, double *imp_time) {
+    return gls_impl(D, guides, n_guides, n, tour, init_cost, perturbation_moves, first_improvement, max_outer_iters,
+                    time_limit_s, trace_cost, trace_cap, trace_len, penalty_out, outer_iters_out, evals_out,
+                    imp_cost, imp_iter, imp_cap, imp_len, imp_time);
 }
 
 /* Full delta tables (parity with the K3u unit kernels): out[i*(n+1)+j] for 0<i,j<n, NaN elsewhere. */

@@ -59,6 +59,8 @@ def lib():
             _f64p, _f64p, ctypes.c_int, ctypes.c_int, _i32p, ctypes.c_double, ctypes.c_int, ctypes.c_int,
             ctypes.c_int64, ctypes.c_double, _f64p, ctypes.c_int, _intp, _i32p, _i64p, _i64p,
             _f64p, _i64p, ctypes.c_int, _intp]
+        L.gls_oracle_guided_local_search_timed.restype = ctypes.c_double
+        L.gls_oracle_guided_local_search_timed.argtypes = L.gls_oracle_guided_local_search.argtypes + [_f64p]
         for name in ("gls_oracle_two_opt_delta_all", "gls_oracle_relocate_delta_all"):
             getattr(L, name).argtypes = [_i32p, _f64p, ctypes.c_int, _f64p]
         _lib = L
@@ -164,7 +166,8 @@ def local_search(init_tour, init_cost, D, first_improvement=False, trace_cap=1 <
 def guided_local_search(D, guides, init_tour, init_cost, perturbation_moves=30, first_improvement=False,
                         max_outer_iters=-1, time_limit_s=0.0, trace_cap=1 << 20, want_penalty=True, imp_cap=4096):
     """guides: array [G, n, n] fp64.  Returns dict(best_tour, best_cost, trace, penalty, outer_iters, evals,
-    imp_cost, imp_iter, imp_len) -- imp_* = the returned best at every improvement (algorithms.py:143,190-191)."""
+    imp_cost, imp_iter, imp_time, imp_len) -- imp_* = the returned best at every improvement (algorithms.py:143,190-191),
+    imp_time = seconds of wall clock since the search started."""
     D = _d(D)
     guides = _d(guides)
     if guides.ndim == 2:
@@ -178,16 +181,18 @@ def guided_local_search(D, guides, init_tour, init_cost, perturbation_moves=30, 
     evals = ctypes.c_int64(0)
     imp_cost = np.zeros(max(imp_cap, 1), dtype=np.float64)
     imp_iter = np.zeros(max(imp_cap, 1), dtype=np.int64)
+    imp_time = np.zeros(max(imp_cap, 1), dtype=np.float64)
     il = ctypes.c_int(0)
-    best = lib().gls_oracle_guided_local_search(
+    best = lib().gls_oracle_guided_local_search_timed(
         _p(D, _f64p), _p(guides, _f64p), guides.shape[0], n, _p(t, _i32p), float(init_cost),
         int(perturbation_moves), int(first_improvement), int(max_outer_iters), float(time_limit_s),
         _p(trace, _f64p), trace_cap, ctypes.byref(tl), _p(pen, _i32p) if want_penalty else None,
-        ctypes.byref(iters), ctypes.byref(evals), _p(imp_cost, _f64p), _p(imp_iter, _i64p), imp_cap, ctypes.byref(il))
+        ctypes.byref(iters), ctypes.byref(evals), _p(imp_cost, _f64p), _p(imp_iter, _i64p), imp_cap, ctypes.byref(il),
+        _p(imp_time, _f64p))
     k = min(il.value, imp_cap)
     return dict(best_tour=t.tolist(), best_cost=best, trace=trace[:min(tl.value, trace_cap)].copy(),
                 trace_len=tl.value, penalty=pen, outer_iters=iters.value, evals=evals.value,
-                imp_cost=imp_cost[:k].copy(), imp_iter=imp_iter[:k].copy(), imp_len=il.value)
+                imp_cost=imp_cost[:k].copy(), imp_iter=imp_iter[:k].copy(), imp_time=imp_time[:k].copy(), imp_len=il.value)
 
 
 def two_opt_delta_all(tour, D):

@@ -39,7 +39,9 @@ def main():
     write, t_w = read(os.path.join(d, "write_counter_collection.csv"))
     lds, t_l = read(os.path.join(d, "lds_counter_collection.csv"))
     iss, t_i = read(os.path.join(d, "issue_counter_collection.csv"))
-    instances, simds, cus, xcds = 1024, 1024, 256, 8
+    wl_path = os.path.join(d, "workload.json")            # written by scripts/pmc_gls.sh since round 4; before: TSP100 x 1024, noise
+    workload = json.load(open(wl_path)) if os.path.isfile(wl_path) else None
+    instances, simds, cus, xcds = (workload["instances"] if workload else 1024), 1024, 256, 8
     clock = lds["GRBM_GUI_ACTIVE"] / xcds / t_l                      # the counter is summed over the 8 XCDs
     fetch_b = fetch["FETCH_SIZE"] * 1024                              # KiB as reported (see the module docstring)
     write_b = write["WRITE_SIZE"] * 1024
@@ -58,9 +60,16 @@ def main():
         "wave_wait_frac": lds["SQ_WAIT_ANY"] / lds["SQ_WAVE_CYCLES"],
         "clock_ghz": clock / 1e9,
         "source": f"{os.path.relpath(d, ROOT)}/*_counter_collection.csv: rocprofv3 --kernel-trace --pmc <counters> -- python3 "
-                  "scripts/probe_gls.py 100 1024 2.0 0 noise (4 separate passes: FETCH_SIZE; WRITE_SIZE; SQ LDS set; SQ issue "
+                  + ("scripts/probe_gls.py %d %d 2.0 0 %s" % (workload["n"], workload["instances"], workload["guide"]) if workload
+                     else "scripts/probe_gls.py 100 1024 2.0 0 noise") +
+                  " (4 separate passes: FETCH_SIZE; WRITE_SIZE; SQ LDS set; SQ issue "
                   "set), scripts/pmc_gls.sh, summarised by scripts/pmc_summary.py",
     }
+    if workload:
+        e["workload"] = {k: workload[k] for k in ("n", "instances", "guide")}
+        # measured LDS-pipe fraction by instruction count: LDS wave-instructions issued per second x 2 array cycles (ds_read_b64 /
+        # b32, conflict-free: MI355X_MICROARCH.md LDS table) against the CUs' LDS cycles -- the conflict-free floor of lds_busy_frac
+        e["lds_insts_floor_frac"] = lds["SQ_INSTS_LDS"] * 2 / (cus * t_l * clock)
     print(json.dumps(e, indent=1))
     if "--write" in sys.argv:
         # profiles/traffic_<round>.json, the round taken from the directory name (r03_pmc -> traffic_r03.json)

@@ -40,17 +40,88 @@ def test_bench_line_has_the_contract_keys():
 
 
 def test_roofline_and_cpu_baseline_objects():
+    """Every fraction of the committed line is re-derived from the line's own numbers, and is <= 1 by construction: the
+    primary one is a counter ratio (busy vector-ALU cycles / SIMD cycles), the live one counts EXECUTED evaluations."""
     j = latest_bench()
     r = j["roofline"]
-    # the kernel that owns the timed step is the search kernel: LDS-bound by design
-    assert r["kernel"] == "gls_kernel" and r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == 150000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
-    assert r["delta_evals_per_s"] > 1e10 and r["launches"] == j["steps"] * j["config"]["rounds_per_rank"][0]
+    assert r["kernel"] == "gls_kernel" and r["launches"] == j["steps"] * j["config"]["rounds_per_rank"][0]
+    if r["bound"] == "lds":                                        # lines of rounds 1-3: the algorithmic LDS figure only
+        assert r["unit"] == "GB/s" and r["peak"] == 150000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    else:
+        assert r["bound"] == "valu_issue" and r["unit"] == "G SIMD-cycles/s"
+        pmc = r["pmc"]
+        assert abs(r["frac"] - pmc["valu_busy_frac"]) < 1e-12 and 0 < r["frac"] <= 1
+        assert abs(r["peak"] - 1024 * pmc["clock_ghz"]) < 1e-9 * r["peak"] and abs(r["achieved"] - r["frac"] * r["peak"]) < 1e-9 * r["peak"]
+        # the counters were collected on the workload of the line itself
+        assert r["pmc_matches_workload"] and pmc["workload"]["n"] == j["config"]["n"] and pmc["workload"]["guide"] == "model"
+        # live part: executed <= reference-equivalent evaluations; LDS bytes of the executed ones against the aggregate rate
+        assert 0 < r["executed_evals_per_s"] <= r["reference_equivalent_evals_per_s"]
+        assert abs(r["prune_ratio"] - r["executed_evals_per_s"] / r["reference_equivalent_evals_per_s"]) < 1e-9
+        le = r["lds_executed"]
+        assert le["peak"] == 150000.0 and abs(le["achieved"] - r["executed_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9) < 1e-6 * le["achieved"]
+        assert abs(le["frac"] - le["achieved"] / le["peak"]) < 1e-12 and 0 < le["frac"] <= 1
+        assert abs(r["reference_equivalent_frac"] - r["reference_equivalent_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9 / 150000.0) < 1e-9
+        b = r["binding_resource"]
+        busy = {k[:-len("_busy_frac")]: v for k, v in pmc.items() if k.endswith("_busy_frac")}
+        order = sorted(busy, key=busy.get, reverse=True)
+        assert b["name"] == order[0] + "_issue" and b["frac"] == busy[order[0]] and b["second"] == order[1]
+        # gap-versus-budget of the same timed step: never rises, ends at the headline gap
+        c = j["gap_vs_budget"]
+        assert len(c) >= 3 and all(a["t_s"] < b_["t_s"] for a, b_ in zip(c, c[1:]))
+        assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(c, c[1:]))
+        assert abs(c[-1]["mean_gap_pct"] - j["mean_gap_pct"]) < 1e-9 and abs(c[-1]["budget_t_s"] - j["config"]["time_limit_s"]) < 1e-6
+        q = j["iso_quality"]
+        assert q["budget"] == "per_batch" and q["rounds"] >= 2 and abs(q["instances_per_s"] - q["instances"] / q["wall_s"]) < 1e-9 * q["instances_per_s"]
+        assert q["wall_s"] < 1.1 * q["time_limit_s"] + 1.0 and q["instances_per_s"] > 2 * j["value"]
+        w = j["cpu_baseline"]["whole_box_estimate"]
+        assert abs(w["instances_per_s"] - j["cpu_baseline"]["per_core_value"] * w["physical_cores"]) < 1e-9 * w["instances_per_s"]
+        assert abs(w["gpu_over_whole_box"] - j["value"] / w["instances_per_s"]) < 1e-9 * w["gpu_over_whole_box"]
+        cc = j["cpu_baseline"]["gap_vs_budget"]
+        assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(cc, cc[1:]))
     for k in j["kernels"].values():
         assert k["bound"] in ("hbm", "mfma") and k["peak"] in (8000.0, 157.3)
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["per_core_value"] > 0 and "all" in c["sample"]
+
+
+def test_search_progress_record_helpers():
+    """best_at_times / gap_curve_sums / gap_curve: the gap-versus-budget record of bench.py (test.py:97-117: best_cost =
+    cummin over the progress rows, read at fixed times)."""
+    b = bench_module()
+    imp_cost = np.array([[10., 9., 8., 8., 0.], [5., 5., 0., 0., 0.], [7., 6., 5., 4., 3.]])
+    imp_time = np.array([[0.01, 0.5, 2.0, 9.8, 0.], [0.2, 9.9, 0., 0., 0.], [0.1, 0.2, 0.3, 0.4, 9.7]])
+    imp_len = np.array([4, 2, 9])                                  # third instance: 8 improvements + terminal in a buffer of 5
+    bt, trunc = b.best_at_times(imp_cost, imp_time, imp_len, np.array([50., 40., 30.]), [0.1, 0.3, 1.0, 3.0, np.inf])
+    assert bt.tolist() == [[10., 10., 9., 8., 8.], [40., 5., 5., 5., 5.], [7., 5., 4., 4., 3.]]
+    assert trunc.tolist() == [False, False, True]
+    sums = b.gap_curve_sums(bt[:2], np.array([8., 5.]))
+    assert sums[:, 2].tolist() == [2.0] * 5 and sums[:, 1].tolist() == [0., 1., 1., 2., 2.]
+    assert abs(sums[0, 0] - (25.0 + 700.0)) < 1e-9
+    c = b.gap_curve(sums, [0.1, 0.3, 1.0, 3.0, 9.85], 0.15)
+    assert [p["mean_gap_pct"] for p in c] == [362.5, 12.5, 6.25, 0.0, 0.0] and abs(c[-1]["budget_t_s"] - 10.0) < 1e-12
+    # empty buffers: nothing but the start tour is known
+    bt0, _ = b.best_at_times(np.zeros((2, 0)), np.zeros((2, 0)), np.array([1, 1]), np.array([3., 4.]), [1.0])
+    assert bt0.tolist() == [[3.], [4.]]
+    cores, threads = b.physical_cores()
+    assert 1 <= cores <= threads
+
+
+def test_search_roofline_object_is_self_consistent():
+    b = bench_module()
+    traffic = {"valu_busy_frac": 0.6, "lds_busy_frac": 0.7, "clock_ghz": 2.0, "hbm_bytes_per_instance_second": 10.0,
+               "workload": {"n": 100, "instances": 1024, "guide": "model"}}
+    r = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, traffic, {"n": 100, "instances": 1024, "guide": "model"})
+    assert r["frac"] == 0.6 and r["peak"] == 2048.0 and abs(r["achieved"] - 0.6 * 2048.0) < 1e-9
+    # 4 launches of 1 s over 2 steps -> 2 launches per step; the evaluation counts are one step's
+    assert abs(r["reference_equivalent_evals_per_s"] - 4e9) < 1 and abs(r["executed_evals_per_s"] - 1e9) < 1 and r["prune_ratio"] == 0.25
+    assert r["binding_resource"]["name"] == "lds_issue" and r["binding_resource"]["second"] == "valu"    # sorted, not hard-coded
+    assert r["pmc_matches_workload"] and r["traffic"] == 10.0 * 1024 * 1.0
+    r2 = b.search_roofline(50, 1, 1000.0, 1, 1e9, 1.0, 128, {}, {"n": 50, "instances": 128, "guide": "model"})
+    assert r2["frac"] is None and r2["binding_resource"]["name"] is None and not r2["pmc_matches_workload"] and r2["traffic"] is None
+    assert r2["prune_ratio"] == 1.0 and r2["lds_executed"]["frac"] == r2["reference_equivalent_frac"]
+    r3 = b.search_roofline(100, 1, 1000.0, 1, 1e9, None, 64, {}, {"n": 100, "instances": 64, "guide": "model"})   # no counting instantiation
+    assert r3["prune_ratio"] is None and r3["executed_evals_per_s"] is None and r3["lds_executed"] is None
 
 
 def test_instance_blocks_and_best_known_file(tmp_path):
@@ -74,7 +145,8 @@ def test_instance_blocks_and_best_known_file(tmp_path):
     assert b.load_best_known(str(tmp_path / "none.npz"), 6, 7, 0, 10)[0] is None
 
 
-@pytest.mark.parametrize("traffic", ["traffic_r02.json", "traffic_r03.json"])
+@pytest.mark.parametrize("traffic", [t for t in ("traffic_r02.json", "traffic_r03.json", "traffic_r04.json")
+                                     if os.path.isfile(os.path.join(ROOT, "profiles", t))])
 def test_committed_pmc_figures_follow_from_the_committed_counter_files(traffic):
     """The gls_kernel entry of profiles/traffic_r0*.json (what bench.py prints as roofline.pmc / roofline.traffic) is exactly
     what scripts/pmc_summary.py derives from the counter CSVs it names -- no hand-edited numbers; likewise the forward

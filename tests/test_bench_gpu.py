@@ -20,12 +20,30 @@ def last_json_line(out):
 
 def test_bench_single_rank_small():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
-                                   "--batch", "64", "--time_limit", "0.5", "--cpu_cores", "8"], cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
+                                   "--batch", "64", "--time_limit", "0.5", "--cpu_cores", "8", "--no_gap_bracket"], cwd=ROOT, stderr=subprocess.STDOUT, timeout=600)
     j = last_json_line(out)
     assert j["n_gpus"] == 1 and j["steps"] == 1 and j["unit"] == "instances/s"
     assert 64 / 1.5 < j["value"] < 64 / 0.45
-    assert j["roofline"]["kernel"] == "gls_kernel" and j["roofline"]["bound"] == "lds" and 0 < j["roofline"]["frac"] < 1
-    assert j["roofline"]["launches"] == 1 and j["config"]["rounds_per_rank"] == [1]
+    r = j["roofline"]
+    assert r["kernel"] == "gls_kernel" and r["bound"] == "valu_issue" and 0 < r["frac"] <= 1
+    assert r["launches"] == 1 and j["config"]["rounds_per_rank"] == [1]
+    # 64 instances run on the LDS-penalty store, which has no counting instantiation: the line says so instead of guessing
+    assert r["reference_equivalent_evals_per_s"] > 0 and r["prune_ratio"] is None and r["lds_executed"] is None
+    # search-progress record of the timed step: the gap never rises with the budget, its end point is the headline gap
+    c = j["gap_vs_budget"]
+    assert [p["t_s"] for p in c[:-1]] == [0.1, 0.3] and 0.3 < c[-1]["t_s"] < 0.5      # grid points inside the 0.5 s budget + its end
+    assert all(a["mean_gap_pct"] >= b["mean_gap_pct"] - 1e-12 for a, b in zip(c, c[1:]))
+    assert all(a["at_best_known_pct"] <= b["at_best_known_pct"] + 1e-12 for a, b in zip(c, c[1:]))
+    assert abs(c[-1]["mean_gap_pct"] - j["mean_gap_pct"]) < 1e-9 and abs(c[-1]["budget_t_s"] - 0.5) < 1e-6
+    assert j["improvement_trace_truncated_instances"] == 0
+    # iso-quality pass: 10 device loads of 64 instances inside ONE 0.5 s limit
+    q = j["iso_quality"]
+    assert q["rounds"] == 10 and q["instances"] == 640 and q["budget"] == "per_batch"
+    assert 640 / 1.6 < q["instances_per_s"] < 640 / 0.45 and q["mean_gap_pct"] >= j["mean_gap_pct"] - 1e-9
+    assert j["config"]["residency_utilisation"] == [64 / 1024] and j["config"]["backend"] is None
+    w = j["cpu_baseline"]["whole_box_estimate"]
+    assert w["physical_cores"] >= 1 and w["instances_per_s"] > 0 and w["gpu_over_whole_box"] > 0
+    assert [p["t_s"] for p in j["cpu_baseline"]["gap_vs_budget"]] == [0.1, 0.3, 0.5]
     assert all(k["bound"] in ("hbm", "mfma") for k in j["kernels"].values()) and "ffn_fused" in j["kernels"]
     assert j["cpu_baseline"]["cores"] == 8 and j["cpu_baseline"]["kind"] == "port"
     assert j["watchdog_aborts"] == 0
@@ -40,21 +58,30 @@ def test_bench_one_rank_through_rccl():
     env.pop("GNNGLS_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29532", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-           "--batch", "64", "--time_limit", "0.5", "--no_cpu_baseline"]
+           "--batch", "640", "--time_limit", "0.5", "--no_cpu_baseline", "--no_gap_bracket", "--no_iso_quality"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.STDOUT, timeout=600)
     j = last_json_line(out)
-    assert j["n_gpus"] == 1 and 64 / 1.5 < j["value"] < 64 / 0.45 and j["watchdog_aborts"] == 0
+    assert j["n_gpus"] == 1 and 640 / 1.5 < j["value"] < 640 / 0.45 and j["watchdog_aborts"] == 0
+    # 640 TSP100 instances run on the compact store (the headline's): the counting pass reports what the pruned 2-opt scan saves
+    r = j["roofline"]
+    assert 0 < r["prune_ratio"] < 1 and abs(r["executed_evals_per_s"] - r["prune_ratio"] * r["reference_equivalent_evals_per_s"]) < 1e-3 * r["executed_evals_per_s"]
+    assert 0 < r["lds_executed"]["frac"] < r["reference_equivalent_frac"] < 1.5
     assert j["config"]["rounds_per_rank"] == [1] and len(j["gls_ms_per_rank"]) == 1 and j["mean_gap_pct"] >= 0
+    assert j["config"]["backend"] == "RCCL (nccl)" and "RCCL" in j["config"]["parallelism"] and j["config"]["world_size"] == 1
+    assert j["config"]["collectives_per_step"] == {"gather": 1.0}
 
 
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, GNNGLS_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--batch", "64", "--time_limit", "0.5"]
+           "--batch", "64", "--time_limit", "0.5", "--no_gap_bracket"]
     out = subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.STDOUT, timeout=600)
     j = last_json_line(out)
     assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["backend"] == "gloo" and "gloo" in j["config"]["parallelism"] and "RCCL" not in j["config"]["parallelism"]
+    assert j["config"]["collectives_per_step"] == {"gather": 1.0} and "iso_quality" not in j
+    assert len(j["gap_vs_budget"]) == 3 and abs(j["gap_vs_budget"][-1]["mean_gap_pct"] - j["mean_gap_pct"]) < 1e-9
     assert 128 / 2.5 < j["value"] < 128 / 0.45          # whole-job aggregate over both ranks
     assert "cpu_baseline" not in j                      # rank 0, N=1 only
     assert j["config"]["rounds_per_rank"] == [1, 1] and len(j["gls_ms_per_rank"]) == 2
@@ -74,3 +101,37 @@ def test_bench_strong_scaling_two_ranks_gloo():
     assert j["config"]["rounds_per_rank"] == [3, 3]
     assert 151 / 4.0 < j["value"] < 151 / 1.15          # 3 rounds x 0.4 s
     assert j["mean_gap_pct"] is None and "no best-known file" in j["gap_reference"]       # TSP20 has no committed file
+
+
+def run_ranks(nproc, port, extra, timeout=900):
+    env = dict(os.environ, GNNGLS_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "0",
+           "--no_gap_bracket"] + extra
+    return last_json_line(subprocess.check_output(cmd, cwd=ROOT, env=env, stderr=subprocess.STDOUT, timeout=timeout))
+
+
+def test_bench_eight_ranks_configs3_in_miniature():
+    """The driver's 8-GPU launch of BASELINE configs[3] (a fixed test set cut into 8 contiguous shards, test.py:59), rehearsed
+    with 8 ranks sharing the one GPU over gloo: 1001 TSP20 instances -> shards of 126 x 7 + 119, two rounds of the full budget
+    per rank at a residency of 64, ONE gather per step, every rank bound to device local_rank % visible devices."""
+    j = run_ranks(8, 29541, ["--tsp_n", "20", "--total_instances", "1001", "--time_limit", "0.3", "--guides", "weight",
+                             "--resident_instances", "64"])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and c["total_instances"] == 1001 and c["world_size"] == 8
+    assert c["rounds_per_rank"] == [2] * 8 and c["collectives_per_step"] == {"gather": 1.0} and c["backend"] == "gloo"
+    assert c["device_of_rank"] == [r % c["visible_devices"] for r in range(8)]
+    util = c["residency_utilisation"]
+    assert all(abs(u - 126 / 128) < 1e-12 for u in util[:7]) and abs(util[7] - 119 / 128) < 1e-12
+    assert 1001 / 3.0 < j["value"] < 1001 / 0.6 and j["watchdog_aborts"] == 0      # 2 rounds x 0.3 s, eight ranks on one GPU
+    assert len(j["gls_ms_per_rank"]) == 8 and j["roofline"]["launches"] == 2
+
+
+def test_bench_eight_ranks_configs4_in_miniature():
+    """BASELINE configs[4] per GPU (TSP200, weak scaling: rank r searches its own block, one round) with 8 ranks on the one
+    GPU: 4 instances per rank, the 16-wave compact-store workgroups of TSP200."""
+    j = run_ranks(8, 29542, ["--tsp_n", "200", "--batch", "4", "--time_limit", "0.5", "--guides", "weight"])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and c["total_instances"] == 32 and c["instances_per_gpu"] == 4
+    assert c["rounds_per_rank"] == [1] * 8 and c["collectives_per_step"] == {"gather": 1.0}
+    assert 32 / 2.5 < j["value"] < 32 / 0.45 and j["watchdog_aborts"] == 0 and j["outer_iters_per_instance"] > 10

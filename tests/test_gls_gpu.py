@@ -158,6 +158,43 @@ def test_gls_batch_vs_oracle(ops, n, B, K, variant):
         assert int(r.evals[b]) == o["evals"]
 
 
+@pytest.mark.parametrize("n,B,K", [(33, 8, 6), (64, 8, 4), (100, 16, 4), (200, 4, 2)])
+def test_executed_evaluation_count(ops, n, B, K):
+    """Measurement hook gnngls_profile_set_executed_evals (bench.py's roofline; counting instantiations of the compact-store
+    kernel): executed = reference-equivalent evaluations where no scan is pruned (n < 80, or the pruned scans switched off);
+    with the pruned scans (2-opt from n = 80, relocate from n = 128) strictly fewer -- and the same search result."""
+    rng = np.random.default_rng(4200 + n)
+    D, _ = random_instances(rng, B, n)
+    d = dev(D, torch.float64)
+    g = d[None].contiguous()
+    init = ops.nearest_neighbor(d)
+    cost = ops.tour_cost(init, d)
+    plain = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=K, penalty_bits=-2)
+    out = {}
+    for prune in (1, 0):
+        with ops.gls_prune_mode(prune), ops.executed_evals(B + 3) as x:
+            r = ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=K, penalty_bits=-2)     # compact store
+        torch.cuda.synchronize()
+        out[prune] = (r, x.counts.cpu().numpy())
+    (r1, x1), (r0, x0) = out[1], out[0]
+    ref = r0.evals.cpu().numpy()
+    for r in (r0, r1):                                                             # counting changes no result
+        assert torch.equal(r.best_tour, plain.best_tour) and torch.equal(r.evals, plain.evals)
+        assert_bits(r.best_cost.cpu().numpy(), plain.best_cost.cpu().numpy())
+    assert np.array_equal(x0[:B], ref) and (x0[B:] == 0).all()                 # full scans: every move evaluated once
+    if n < 80:
+        assert np.array_equal(x1[:B], ref)
+    else:
+        assert (x1[:B] > 0).all() and (x1[:B] < ref).all()
+        if n >= 128:                                                              # both descent scans pruned
+            assert (x1[:B] < 0.5 * ref).all()
+        # a pruning run on a store without the counting instantiations says so instead of guessing
+        with ops.executed_evals(B) as x:
+            ops.gls_run(d, g, init, cost, perturbation_moves=20, max_outer_iters=1, penalty_bits=32)
+        if ops.gls_describe_config(n, B, 32)["store"] == "lds-tri-i32":
+            assert (x.counts.cpu().numpy() == -1).all()
+
+
 @pytest.mark.parametrize("n,B,K,bits,store,per_cu", [
     (131, 3, 2, -2, "compact", 2), (131, 3, 2, 0, "lds-tri-i32", 1), (160, 3, 2, -2, "compact", 1),
     (160, 3, 2, 0, "lds-tri-i32", 1), (200, 3, 2, 0, "compact", 1), (200, 2, 1, -2, "compact", 1)])
