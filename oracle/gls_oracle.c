@@ -237,6 +237,16 @@ static double now_s(void) {
  *            terminal entry (best_cost, outer iterations completed); *imp_len counts all of them
  * Returns best_cost.
  */
+/* Diagnostics for kernel design (scripts/perturbation_stats.py): per penalty step, which of the four one-to-all scans
+ * (2 endpoint + operator) accepted the step's FIRST move (index 4: none), and how many moves each scan accepted. */
+static int64_t g_first_move_hist[5], g_scan_moves[4], g_steps;
+void gls_oracle_perturbation_stats(int64_t *first_move_hist5, int64_t *scan_moves4, int64_t *steps, int reset) {
+    for (int q = 0; q < 5; ++q) { if (first_move_hist5) first_move_hist5[q] = g_first_move_hist[q]; if (reset) g_first_move_hist[q] = 0; }
+    for (int q = 0; q < 4; ++q) { if (scan_moves4) scan_moves4[q] = g_scan_moves[q]; if (reset) g_scan_moves[q] = 0; }
+    if (steps) *steps = g_steps;
+    if (reset) g_steps = 0;
+}
+
 static double gls_impl(const double *D, const double *guides, int n_guides, int n,
                                       int32_t *tour, double init_cost,
                                       int perturbation_moves, int first_improvement,
@@ -289,6 +299,7 @@ static double gls_impl(const double *D, const double *guides, int n_guides, int 
                 DIDX(Dg, n, ev, eu) = DIDX(D, n, ev, eu) + kp;
             }
             int ends[2] = { eu, ev };
+            int first_move = 4;
             for (int s = 0; s < 2; ++s) {                         /* :167 */
                 int node = ends[s];
                 if (node == 0) continue;                          /* :168 */
@@ -303,9 +314,12 @@ static double gls_impl(const double *D, const double *guides, int n_guides, int 
                         cur_cost = gls_oracle_tour_cost(cur, D, n);   /* :176 real weights */
                         trace_push(&tr, cur_cost);
                         moves += 1;                               /* :185 */
+                        g_scan_moves[2 * s + op] += 1;
+                        if (first_move == 4) first_move = 2 * s + op;
                     }
                 }
             }
+            g_first_move_hist[first_move] += 1; g_steps += 1;
         }
         local_search_impl(cur, &cur_cost, D, n, first_improvement, &tr, &evals);   /* :188 */
         if (cur_cost < best_cost) {                               /* :190-191 */
