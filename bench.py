@@ -182,10 +182,11 @@ def search_roofline(n, steps, gls_ms, gls_launches, ref_evals, exec_ratio, resid
     per_launch = lambda evals: evals / launches_per_step / avg_launch_s if avg_launch_s > 0 else 0.0   # noqa: E731
     ref_rate = per_launch(ref_evals)
     exec_rate = ref_rate * exec_ratio if exec_ratio is not None else None
+    matches = bool(traffic.get("workload")) and all(traffic["workload"].get(k) == v for k, v in workload.items())
     busy = {k[:-len("_busy_frac")]: traffic[k] for k in traffic if k.endswith("_busy_frac") and traffic[k] is not None}
     order = sorted(busy, key=busy.get, reverse=True)
     clock = traffic.get("clock_ghz")
-    valu = busy.get("valu")
+    valu = busy.get("valu") if matches else None             # counters of another workload say nothing about this one
     out = {
         "kernel": "gls_kernel", "bound": "valu_issue",
         # busy vector-ALU cycles per second over all SIMDs against the SIMD cycles per second (PMC: SQ_ACTIVE_INST_VALU x 4)
@@ -193,7 +194,7 @@ def search_roofline(n, steps, gls_ms, gls_launches, ref_evals, exec_ratio, resid
         "peak": N_SIMDS * clock if clock else None, "unit": "G SIMD-cycles/s",
         "frac": valu,
         "traffic": traffic["hbm_bytes_per_instance_second"] * resident * avg_launch_s
-        if "hbm_bytes_per_instance_second" in traffic else None,
+        if matches and "hbm_bytes_per_instance_second" in traffic else None,
         "avg_launch_ms": avg_launch_s * 1e3, "launches": int(gls_launches), "resident_instances": resident,
         "executed_evals_per_s": exec_rate, "reference_equivalent_evals_per_s": ref_rate,
         "prune_ratio": exec_ratio,
@@ -206,10 +207,11 @@ def search_roofline(n, steps, gls_ms, gls_launches, ref_evals, exec_ratio, resid
                                         "valu_insts_per_s", "lds_insts_per_s", "hbm_gbs", "clock_ghz", "workload", "source")
                 if k in traffic},
         # the busiest pipes according to those counters (null without counters)
-        "binding_resource": {"name": (order[0] + "_issue") if order else None, "frac": busy[order[0]] if order else None,
-                             "second": order[1] if len(order) > 1 else None,
-                             "second_frac": busy[order[1]] if len(order) > 1 else None},
-        "pmc_matches_workload": bool(traffic.get("workload")) and all(traffic["workload"].get(k) == v for k, v in workload.items()),
+        "binding_resource": {"name": (order[0] + "_issue") if order and matches else None,
+                             "frac": busy[order[0]] if order and matches else None,
+                             "second": order[1] if len(order) > 1 and matches else None,
+                             "second_frac": busy[order[1]] if len(order) > 1 and matches else None},
+        "pmc_matches_workload": matches,
         "note": "frac = busy fraction of the vector ALUs (committed PMC passes, `pmc`).  reference_equivalent_evals_per_s is "
                 "measured on the timed launches (HIP events + the kernel's counter of what the reference evaluates); prune_ratio = "
                 "executed / reference-equivalent evaluations of a %g s untimed pass of the same workload on the counting "
@@ -566,8 +568,11 @@ def main():
         # dominant kernel of the timed step: the search kernel (by construction it runs for the whole budget).  One launch
         # per round; duration from the HIP events recorded around the launch on its stream.  Rank 0's launches, last step's
         # evaluation counts (reference-equivalent: evals_out; executed: the measurement hook).
-        traffic = load_traffic().get("gls_kernel", {})
         resident = min(chunk_eff, B)
+        # counters collected on this very workload if there are any (profiles/traffic_r0*.json: `gls_kernel@tsp<n>x<B>`), else the
+        # headline's -- search_roofline() then withholds the fractions (pmc_matches_workload false)
+        traffic = load_traffic()
+        traffic = traffic.get("gls_kernel@tsp%dx%d" % (n, resident), traffic.get("gls_kernel", {}))
         ratio = per_rank[0][3].item()
         roof = search_roofline(n, args.steps, gls_ms, gls_launches, per_rank[0][4].item(), ratio if ratio >= 0 else None, resident, traffic,
                                {"n": n, "instances": resident, "guide": "model" if args.guides == ["regret_pred"] else "+".join(args.guides)})

@@ -76,7 +76,10 @@ def main():
         rnd = os.path.basename(os.path.normpath(d)).split("_")[0][:3]
         p = os.path.join(ROOT, "profiles", f"traffic_{rnd}.json")
         t = json.load(open(p)) if os.path.isfile(p) else {}
-        t["gls_kernel"] = e
+        # the headline workload (TSP100 x 1024) is the `gls_kernel` entry; other workloads get a key of their own
+        key = "gls_kernel" if not workload or (workload["n"], workload["instances"]) == (100, 1024) else \
+            "gls_kernel@tsp%dx%d" % (workload["n"], workload["instances"])
+        t[key] = e
         json.dump(t, open(p, "w"), indent=1)
         print("updated", p)
 

@@ -117,6 +117,10 @@ def test_search_roofline_object_is_self_consistent():
     assert abs(r["reference_equivalent_evals_per_s"] - 4e9) < 1 and abs(r["executed_evals_per_s"] - 1e9) < 1 and r["prune_ratio"] == 0.25
     assert r["binding_resource"]["name"] == "lds_issue" and r["binding_resource"]["second"] == "valu"    # sorted, not hard-coded
     assert r["pmc_matches_workload"] and r["traffic"] == 10.0 * 1024 * 1.0
+    # counters of another workload: kept for reference, no fraction derived from them
+    rm = b.search_roofline(200, 1, 1000.0, 1, 1e9, 0.03, 256, traffic, {"n": 200, "instances": 256, "guide": "model"})
+    assert rm["frac"] is None and rm["traffic"] is None and rm["binding_resource"]["name"] is None and not rm["pmc_matches_workload"]
+    assert rm["pmc"]["valu_busy_frac"] == 0.6
     r2 = b.search_roofline(50, 1, 1000.0, 1, 1e9, 1.0, 128, {}, {"n": 50, "instances": 128, "guide": "model"})
     assert r2["frac"] is None and r2["binding_resource"]["name"] is None and not r2["pmc_matches_workload"] and r2["traffic"] is None
     assert r2["prune_ratio"] == 1.0 and r2["lds_executed"]["frac"] == r2["reference_equivalent_frac"]
