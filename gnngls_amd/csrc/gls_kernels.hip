@@ -60,6 +60,9 @@ namespace gnngls {
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
 #endif
+#ifndef GLS_PEN_BUFFER
+#define GLS_PEN_BUFFER 1             // compact store: penalty counters through a raw buffer descriptor (32-bit offsets)
+#endif
 #ifndef GLS_SKIP_DEAD_PASS
 #define GLS_SKIP_DEAD_PASS 1         // pruned descent scans: a wavefront without rows in a pass skips it
 #endif
@@ -154,6 +157,11 @@ struct TriStore {
 struct TriDGlobalP {
     const double *d;   // LDS
     int32_t *p;        // global, packed triangle
+#if GLS_PEN_BUFFER
+    // the same triangle as a raw buffer: loads and stores take a 32-bit byte offset (buffer_load_dword ... offen) instead of
+    // a 64-bit per-lane address -- no sign extension and 64-bit add per scattered counter load of the guided scans
+    __amdgpu_buffer_rsrc_t prs;
+#endif
     using pen_t = int32_t;
     using tour_t = uint8_t;                       // n <= 255
     static constexpr bool kSymmetric = true;
@@ -165,17 +173,26 @@ struct TriDGlobalP {
         return ((hi * (hi - 1)) >> 1) + lo;
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
-    __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
     // index with the triangular row offsets precomputed: a2 = a(a-1)/2 (per lane), c2 = c(c-1)/2 (wave-uniform, SALU)
     __device__ __forceinline__ static int idx2(int a, int a2, int c, int c2) { return a > c ? a2 + c : c2 + a; }
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
+#if GLS_PEN_BUFFER
+    __device__ __forceinline__ void bind(int ntri) { prs = __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, ntri * 4, 0x00020000); }
+    __device__ __forceinline__ int pen_at(int q) const { return __builtin_amdgcn_raw_buffer_load_b32(prs, q << 2, 0, 0); }
+    __device__ __forceinline__ void pen_store(int q, int v) const { __builtin_amdgcn_raw_buffer_store_b32(v, prs, q << 2, 0, 0); }
+#else
+    __device__ __forceinline__ void bind(int) {}
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
+    __device__ __forceinline__ void pen_store(int q, int v) const { p[q] = v; }
+#endif
+    __device__ __forceinline__ int pen(int a, int b) const { return pen_at(idx(a, b)); }
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
-        p[idx(a, b)] += 1;
+        const int q = idx(a, b);
+        pen_store(q, pen_at(q) + 1);
         return false;
     }
     __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {   // no read-back: store only
-        p[idx(a, b)] = old_count + 1;
+        pen_store(idx(a, b), old_count + 1);
         return false;
     }
 };
@@ -1859,6 +1876,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
             s.p = A.pen_ws + (size_t)b * nn; s.n = n;                         // full matrix, zeroed by the host
         } else {
             s.p = A.pen_ws + (size_t)b * ntri;                                // zeroed by the host
+            s.bind(ntri);
         }
     } else {
         s.d = Dg; s.p = A.pen_ws + (size_t)b * nn; s.n = n;                   // workspace zeroed by the host

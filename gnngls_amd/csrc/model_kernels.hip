@@ -32,6 +32,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed fp32 (two lanes of work per instruction); the compiler scalarises <2 x float> arithmetic next to scalar selects
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// one v_max_f32: fmaxf() on values that come out of inline asm gets a canonicalising v_max_f32 x, x, x per operand first
+// (three instructions per maximum)
+__device__ __forceinline__ float max_f32(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 constexpr int kD = 128;        // embed_dim
 constexpr int kH = 8;          // heads
@@ -402,14 +405,13 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
             auto body = [&](int s0, auto masked) {
                 constexpr bool MASK = decltype(masked)::value;
                 int sidx[2]; bool live[2];
-                f32x4 e[2], ea[2], eb[2];
+                f32x4 ea[2], eb[2];
                 float bv[2][HU];
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const int s = s0 + 4 * g + kq;
                     sidx[g] = MASK ? (s < ns ? s : ns - 1) : s;
                     live[g] = (s < ns) && (s != js);              // no self loop, no padding
-                    e[g] = *reinterpret_cast<const f32x4 *>(elS + sidx[g] * HS + h0);
                     ea[g] = *reinterpret_cast<const f32x4 *>(eaS + sidx[g] * HS + h0);
                     eb[g] = *reinterpret_cast<const f32x4 *>(ebS + sidx[g] * HS + h0);
 #pragma unroll
@@ -425,8 +427,11 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                         f32x2 w;
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            const int u = 2 * hp + c;
-                            float x = e[g][u] > ner[u] ? wp[c] : wn[c];
+                            // exp is monotone and LeakyReLU(x) = max(x, 0.2 x): exp(LeakyReLU(x) - m) = max(exp(x - m),
+                            // exp(0.2 x - m)) -- one v_max_f32 instead of a compare against the logits and a select, and the
+                            // el table is not read in this loop at all (where the two products are within rounding of each
+                            // other, x ~ 0, either is the weight to ~1 ulp)
+                            float x = max_f32(wp[c], wn[c]);
                             if (MASK) x = live[g] ? x : 0.f;
                             w[c] = x;
                         }
