@@ -28,7 +28,7 @@ def read(path):
 
 def main():
     d = sys.argv[1]
-    rows_per_launch = float(sys.argv[2]) if len(sys.argv) > 2 else 512 * 4950.0
+    rows_per_launch = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 512 * 4950.0
     out = {}
     mf, t_m, _ = read(os.path.join(d, "mfma_counter_collection.csv"))
     va, t_v, _ = read(os.path.join(d, "valu_counter_collection.csv"))
@@ -53,6 +53,18 @@ def main():
         out[k]["avg_launch_ms"] = t_f[k] / max(n_f[k], 1) * 1e3
     out["source"] = f"{d}/*_counter_collection.csv (scripts/pmc_forward.sh: predict_regret, 512 TSP100 instances)"
     print(json.dumps(out, indent=1))
+    if "--write" in sys.argv:
+        # merge into profiles/traffic_<round>.json under the names bench.py uses (round from the directory name: r04_pmc_forward)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        rel = os.path.relpath(d, root)
+        rnd = os.path.basename(os.path.normpath(d)).split("_")[0][:3]
+        path = os.path.join(root, "profiles", f"traffic_{rnd}.json")
+        table = json.load(open(path)) if os.path.isfile(path) else {}
+        for name, kern in (("ffn_fused", "ffn_fused_kernel"), ("gemm_fc", "gemm_f32_kernel"), ("gat_aggregate", "gat_rows_kernel")):
+            if kern in out:
+                table[name] = dict(out[kern], source=f"{rel}/*_counter_collection.csv (scripts/pmc_forward.sh: predict_regret, 512 TSP100 instances)")
+        json.dump(table, open(path, "w"), indent=1)
+        print("updated", path, file=sys.stderr)
 
 
 if __name__ == "__main__":
