@@ -103,3 +103,36 @@ def test_misc():
     assert go.nearest_neighbor(g["nn_W_weight"]) == g["nn_tour_weight"].tolist()
     assert go.nearest_neighbor(g["nn_W_regret"]) == g["nn_tour_regret"].tolist()
     assert_bits(go.tour_cost(g["tc_tour"], g["nn_W_weight"]), g["tc_cost"])
+
+
+def test_timed_improvement_trace_and_perturbation_statistics():
+    """Round-4 additions of the oracle (bench.py's CPU leg, kernel-design diagnostics): the timed improvement trace is the plain
+    one plus non-decreasing wall-clock stamps; the per-step statistics add up."""
+    import ctypes
+    from oracle import gls_oracle as go
+    rng = np.random.default_rng(5)
+    n = 30
+    pos = rng.random((n, 2))
+    D = np.sqrt(((pos[:, None] - pos[None]) ** 2).sum(-1))
+    D = np.triu(D, 1)
+    D = D + D.T
+    init = go.nearest_neighbor(D)
+    c0 = go.tour_cost(init, D)
+    L = go.lib()
+    i64 = ctypes.c_int64
+    L.gls_oracle_perturbation_stats.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.c_int]
+    L.gls_oracle_perturbation_stats(None, None, None, 1)                       # reset
+    r = go.guided_local_search(D, D[None], init, c0, perturbation_moves=20, max_outer_iters=200, trace_cap=1 << 16)
+    k = len(r["imp_cost"])
+    assert k == min(r["imp_len"], 4096) and len(r["imp_time"]) == k and len(r["imp_iter"]) == k
+    assert (np.diff(r["imp_time"]) >= 0).all() and r["imp_time"][0] >= 0
+    assert (np.diff(r["imp_cost"][:-1]) < 0).all() and r["imp_cost"][-1] == r["best_cost"] == r["imp_cost"][-2]
+    assert r["imp_iter"][-1] == 200 and (np.diff(r["imp_iter"]) >= 0).all()
+    h, m, st = (i64 * 5)(), (i64 * 4)(), i64()
+    L.gls_oracle_perturbation_stats(h, m, ctypes.byref(st), 0)
+    h, m = np.array(h[:]), np.array(m[:])
+    assert h.sum() == st.value > 0 and (h >= 0).all()
+    # every step with a first move at scan q accepted at least that move; moves counted per scan never exceed the steps
+    assert (m <= st.value).all() and m.sum() >= st.value - h[4] and (m >= h[:4]).all()
+    # the perturbation phase of 200 outer iterations accepted >= 20 moves each (algorithms.py:151: `while moves < perturbation_moves`)
+    assert m.sum() >= 200 * 20
