@@ -60,6 +60,9 @@ namespace gnngls {
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
 #endif
+#ifndef GLS_TEAM_NODE_SUBST
+#define GLS_TEAM_NODE_SUBST 1        // team form: known-count substitution decided by node compares (uniform part on the scalar unit)
+#endif
 #ifndef GLS_PEN_BUFFER
 #define GLS_PEN_BUFFER 1             // compact store: penalty counters through a raw buffer descriptor (32-bit offsets)
 #endif
@@ -1409,9 +1412,12 @@ __device__ __forceinline__ double tour_cost_from_edges(const double *Ef, int n) 
 // One pass (j = j0 + lane) of the guided one-to-all scans for the row-major penalty matrix of TriDGlobalPF: same operands,
 // same arithmetic as scan_*_o2a_guided; a counter is read at [wave-uniform node][the lane's node] wherever the pair has a
 // wave-uniform node.  (qk1, qk2) are the two matrix cells of the edge this penalty step incremented, pk its new count.
+// eu, ev: the nodes of that edge.  Which counters can BE that edge is mostly decided on the scalar unit (GLS_TEAM_NODE_SUBST):
+// a pair with a wave-uniform node matches iff its other node is the edge's other endpoint -- one vector compare instead of
+// two per pair, none for the pairs of two uniform nodes; only the lane's own tour edge keeps the two-cell test.
 template <class S, bool FI, class TT>
 __device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k, const TT *t, int n, int i, int j,
-                                                           int qk1, int qk2, int pk, double &bd, int &bk) {
+                                                           int qk1, int qk2, int pk, int eu, int ev, double &bd, int &bk) {
     int dj = i - j; if (dj < 0) dj = -dj;
     if (j > n - 1 || dj < 2) return;                         // operators.py:61-62
     const bool lt = i < j;
@@ -1426,8 +1432,22 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k,
     // all counter loads in flight before the first one is consumed: left alone, the compiler sinks each load to its
     // substitution below and waits for it there -- four (relocate: three) memory round trips in a row per unit
     asm volatile("" : "+v"(p0), "+v"(p1), "+v"(pu), "+v"(pl));
+#if GLS_TEAM_NODE_SUBST
+    {
+        const int ti_u = __builtin_amdgcn_readfirstlane(ti), tim_u = __builtin_amdgcn_readfirstlane(tim);
+        const int oth_i = ti_u == eu ? ev : (ti_u == ev ? eu : -1);          // the node that makes {t[i], x} the incremented edge
+        const int oth_im = tim_u == eu ? ev : (tim_u == ev ? eu : -1);
+        p0 = tj == oth_i ? pk : p0;                          // {t[i], t[j]}
+        p1 = tjm == oth_im ? pk : p1;                        // {t[i-1], t[j-1]}
+        pu = tim_u == oth_i ? pk : pu;                       // {t[i], t[i-1]}: both uniform
+        pl = (rl == qk1 || rl == qk2) ? pk : pl;             // the lane's tour edge
+        (void)r0; (void)r1; (void)ru;
+    }
+#else
+    (void)eu; (void)ev;
     p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1;
     pu = (ru == qk1 || ru == qk2) ? pk : pu; pl = (rl == qk1 || rl == qk2) ? pk : pl;
+#endif
     const double g0 = d0 + k * (double)p0, g1 = d1 + k * (double)p1;   // [exact] product rounded, then sum
     const double gu = du + k * (double)pu, gl = dl + k * (double)pl;
     double delta = g0 + g1;                                  // operators.py:25-28, left to right
@@ -1438,7 +1458,7 @@ __device__ __forceinline__ void scan_two_opt_o2a_guided_rm(const S &s, double k,
 
 template <class S, bool FI, class TT>
 __device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k, const TT *t, int n, int i, int j,
-                                                            int qk1, int qk2, int pk, double &bd, int &bk) {
+                                                            int qk1, int qk2, int pk, int eu, int ev, double &bd, int &bk) {
     const int a = t[i - 1], b = t[i], c = t[i + 1];
     const int rab = b * n + a, rbc = b * n + c, rac = a * n + c;
     int pab = s.cell(rab), pbc = s.cell(rbc), pac = s.cell(rac);
@@ -1451,8 +1471,22 @@ __device__ __forceinline__ void scan_relocate_o2a_guided_rm(const S &s, double k
     const double dab = s.dist(a, b), dbc = s.dist(b, c), dac = s.dist(a, c);
     const double d0 = s.dist(d, e), d1 = s.dist(d, b), d2 = s.dist(b, e);
     asm volatile("" : "+v"(pab), "+v"(pbc), "+v"(pac), "+v"(p0), "+v"(p1), "+v"(p2));      // see scan_two_opt_o2a_guided_rm
+#if GLS_TEAM_NODE_SUBST
+    {
+        const int a_u = __builtin_amdgcn_readfirstlane(a), b_u = __builtin_amdgcn_readfirstlane(b), c_u = __builtin_amdgcn_readfirstlane(c);
+        const int oth_b = b_u == eu ? ev : (b_u == ev ? eu : -1);
+        const int oth_a = a_u == eu ? ev : (a_u == ev ? eu : -1);
+        pab = a_u == oth_b ? pk : pab; pbc = c_u == oth_b ? pk : pbc; pac = c_u == oth_a ? pk : pac;      // uniform pairs
+        p0 = (r0 == qk1 || r0 == qk2) ? pk : p0;             // the lane's tour edge {d, e}
+        p1 = d == oth_b ? pk : p1;                           // {d, b}
+        p2 = e == oth_b ? pk : p2;                           // {b, e}
+        (void)rab; (void)rbc; (void)rac; (void)r1; (void)r2;
+    }
+#else
+    (void)eu; (void)ev;
     pab = (rab == qk1 || rab == qk2) ? pk : pab; pbc = (rbc == qk1 || rbc == qk2) ? pk : pbc; pac = (rac == qk1 || rac == qk2) ? pk : pac;
     p0 = (r0 == qk1 || r0 == qk2) ? pk : p0; p1 = (r1 == qk1 || r1 == qk2) ? pk : p1; p2 = (r2 == qk1 || r2 == qk2) ? pk : p2;
+#endif
     const double gab = dab + k * (double)pab, gbc = dbc + k * (double)pbc, gac = dac + k * (double)pac;
     double base = -gab;                                      // operators.py:97-99, left to right
     base = base - gbc;
@@ -1578,8 +1612,8 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
                     const int i = sc >= 2 ? i1 : bp;
                     if constexpr (PenRowMajor<S>::value) {
                         const int j = 1 + pass * kWave + lane;
-                        if ((sc & 1) == 0) scan_two_opt_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, bd, bk);
-                        else               scan_relocate_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, bd, bk);
+                        if ((sc & 1) == 0) scan_two_opt_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, eu, ev, bd, bk);
+                        else               scan_relocate_o2a_guided_rm<S, FI>(s, k, t, n, i, j, q_inc, q_inc2, p_inc, eu, ev, bd, bk);
                     } else {
                         if ((sc & 1) == 0) scan_two_opt_o2a_guided<S, FI, TT, true>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n, q_inc, p_inc);
                         else               scan_relocate_o2a_guided<S, FI, TT, true>(s, k, t, n, i, lane, bd, bk, 1 + pass * kWave, n, q_inc, p_inc);
