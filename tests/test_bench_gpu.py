@@ -26,7 +26,9 @@ def test_bench_single_rank_small():
     assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["unit"] == "instances/s"
     assert 64 / 1.5 < j["value"] < 64 / 0.45
     r = j["roofline"]
-    assert r["kernel"] == "gls_kernel" and r["bound"] == "valu_issue" and 0 < r["frac"] <= 1
+    # the committed counters are the headline's (TSP100 x 1024): for this 64-instance run the fractions are withheld, not borrowed
+    assert r["kernel"] == "gls_kernel" and r["bound"] == "valu_issue" and r["frac"] is None and not r["pmc_matches_workload"]
+    assert r["pmc"]["workload"] == {"n": 100, "instances": 1024, "guide": "model"} and r["binding_resource"]["name"] is None
     assert r["launches"] == 1 and j["config"]["rounds_per_rank"] == [1]
     # 64 instances run on the LDS-penalty store, which has no counting instantiation: the line says so instead of guessing
     assert r["reference_equivalent_evals_per_s"] > 0 and r["prune_ratio"] is None and r["lds_executed"] is None
