@@ -103,7 +103,7 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0, bool first_improv
 // sits in the LDS slot the best tour used to have, so the footprint does not change)
 GlsConfig gls_config_run(int n, int requested_bits, int batch, bool first_improvement) {
     GlsConfig c = gls_config(n, requested_bits, batch, first_improvement);
-    c.prune = g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement);
+    c.prune = g_prune_mode.load(std::memory_order_relaxed) != 0 && gnngls::gls_prune_supported(c.store, n, first_improvement, c.wps);
     return c;
 }
 

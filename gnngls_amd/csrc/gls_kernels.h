@@ -57,7 +57,7 @@ bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
 constexpr int kNeighborListLen = 32;
-bool gls_prune_supported(int store, int n, bool first_improvement);
+bool gls_prune_supported(int store, int n, bool first_improvement, int wps);
 bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool trace);
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);

@@ -60,6 +60,10 @@ namespace gnngls {
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
 #endif
+#ifndef GLS_PRUNE_MAX_WPS
+#define GLS_PRUNE_MAX_WPS 6          // register budgets (waves per SIMD) whose instantiations carry the pruned descent scans: not the
+                                     // 64-VGPR builds (batches of small instances: scratch 148 -> 100 B, +0.8 %; profiles/r04_experiments)
+#endif
 #ifndef GLS_TEAM_NODE_SUBST
 #define GLS_TEAM_NODE_SUBST 1        // team form: known-count substitution decided by node compares (uniform part on the scalar unit)
 #endif
@@ -1718,7 +1722,7 @@ struct PruneCtx {
     NlWords nlw; bool on;
 };
 
-template <class S, bool FI, int GP, bool CNT, class TT, class TRC>
+template <class S, bool FI, int GP, bool CNT, bool PRUNE_OK, class TT, class TRC>
 __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, long long &xe, Stamps &st,
                                  TT *ppos, const PruneCtx &pc) {
@@ -1727,7 +1731,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // pruned descent scans (given neighbour lists): the 2-opt scan from n = 80 up, the relocate scan from n = 128 up (the
     // 4-slot instantiations) -- where each was measured faster (profiles/r03_experiments/README.md)
-    constexpr bool kCanPrune = !FI && S::kSymmetric;
+    constexpr bool kCanPrune = !FI && S::kSymmetric && PRUNE_OK;
     constexpr bool kPruneRelocate = kCanPrune && GP == 4;
     const bool prune = kCanPrune && pc.on;
     double Lmax = 0.0;
@@ -1955,7 +1959,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
     if (!FI && nthr > kWave) { block_reduce_lds_init(ctl, tid); __syncthreads(); }
     STAMP_BEGIN();
     PruneCtx pc{{0u, 0u, 0u, 0u}, false};
-    if constexpr (!FI && S::kSymmetric) {
+    if constexpr (!FI && S::kSymmetric && WPS <= GLS_PRUNE_MAX_WPS) {
         // (a workgroup too small to hold its rows' list words in kNlPasses registers per lane runs the full scans)
         if (A.nl_id && A.prune_ok[b] && 8 * (n - 1) <= kNlPasses * nthr) {
             const uint8_t *nl = A.nl_id + (size_t)b * n * kNL;
@@ -1971,7 +1975,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         }
     }
     long long xe = 0;        // executed minus reference-equivalent evaluations of this wavefront's pruned scans (CNT builds)
-    local_search_dev<S, FI, GP, CNT>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
+    local_search_dev<S, FI, GP, CNT, (WPS <= GLS_PRUNE_MAX_WPS)>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
@@ -2126,7 +2130,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI, GP, CNT>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
+        local_search_dev<S, FI, GP, CNT, (WPS <= GLS_PRUNE_MAX_WPS)>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -2436,8 +2440,8 @@ bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool
 
 // pruned descent scans exist in the 4-slot instantiations of the symmetric stores (n >= 128), best improvement only; the
 // lists must be full (n - 1 >= 32)
-bool gls_prune_supported(int store, int n, bool first_improvement) {
-    return store != GLS_STORE_GLOBAL && !first_improvement && n >= kPruneMinNodes && n <= 255;
+bool gls_prune_supported(int store, int n, bool first_improvement, int wps) {
+    return store != GLS_STORE_GLOBAL && !first_improvement && n >= kPruneMinNodes && n <= 255 && wps <= GLS_PRUNE_MAX_WPS;
 }
 
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream) {
