@@ -114,6 +114,7 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_impr
     const int cus = num_cus();
     // candidates are visited fastest store first (LDS penalties 32-bit, LDS penalties 16-bit, compact); the first one
     // that keeps the whole batch resident wins, otherwise the one with the most resident workgroups per CU
+    auto by_lds_of = [](size_t lds) { return (int)(kLdsPerCU / lds); };
     auto consider = [&](int store, int bits) {
         if (done) return;
         size_t lds = gnngls::gls_lds_bytes(n, store, bits);
@@ -143,6 +144,13 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_impr
         // wavefront per instance: measured TSP30 x 8192, 1 s -- 64 threads keep all 8192 resident, 6.2k iterations each;
         // 128 threads halve the residency: 8.8k iterations each in two rounds of 1 s, half the aggregate rate
         // (profiles/r04_ab_threads_tsp30x8192.log))
+        // batches of at most two single-wavefront workgroups per SIMD: the 256-VGPR build of the one-slot kernel
+        // (not while the test hook forces the team form, which only exists on the 128-VGPR build)
+        if (wps == 4 && batch > 0 && g_team_mode.load(std::memory_order_relaxed) != 1 &&
+            gnngls::gls_wps2_supported(store, bits, n, threads, first_improvement)) {
+            const int per2 = by_lds_of(lds) < 8 ? by_lds_of(lds) : 8;
+            if ((long)per2 * cus >= batch) wps = 2;
+        }
         const int by_waves = (wps * 4) / (threads / 64);
         int per_cu = (int)(kLdsPerCU / lds);
         if (per_cu > by_waves) per_cu = by_waves;

@@ -54,6 +54,7 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
 // team: perturbation phase on all wavefronts of the workgroup (for workgroups that own their CU); only where
 // gls_team_supported() says so
 bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads);
+bool gls_wps2_supported(int store, int penalty_bits, int n, int threads, bool first_improvement);
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
 constexpr int kNeighborListLen = 32;

@@ -60,6 +60,10 @@ namespace gnngls {
 #define GLS_NODE_LANES 0             // relocate descent scan: lanes own tour positions (0) or node ids (1: 21 % fewer LDS
                                      // bank-conflict cycles, 1 % FEWER iterations -- profiles/r03_experiments/README.md)
 #endif
+#ifndef GLS_WPS2
+#define GLS_WPS2 1                   // 256-VGPR build of the one-slot kernel for batches of <= 2 single-wavefront workgroups per SIMD (TSP20 x 1000:
+                                     // groups of 4 steps in the half-wave scans without scratch, +3 %; profiles/r04_experiments)
+#endif
 #ifndef GLS_PRUNE_MAX_WPS
 #define GLS_PRUNE_MAX_WPS 6          // register budgets (waves per SIMD) whose instantiations carry the pruned descent scans: not the
                                      // 64-VGPR builds (batches of small instances: scratch 148 -> 100 B, +0.8 %; profiles/r04_experiments)
@@ -927,7 +931,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
 #endif
 constexpr int kHalfScanMinNodes = 8, kHalfScanMaxNodes = 33;
 
-template <class S, class TT>
+template <int HUN, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_lean_half(const S &s, const TT *t, const double *Ef, int n, int lane,
                                                             double &bd, int &bk) {
     const bool hi = lane >= 32;
@@ -977,17 +981,17 @@ __device__ __forceinline__ void scan_relocate_a2a_lean_half(const S &s, const TT
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_HALF_UNROLL>;
+    using UN = std::integral_constant<int, HUN>;
     using U1 = std::integral_constant<int, 1>;
     using FAST = std::integral_constant<bool, false>;
     using SAFE = std::integral_constant<bool, true>;
     int ss = 0;
-    for (; ss + GLS_HALF_UNROLL <= K0 - 2; ss += GLS_HALF_UNROLL) group(ss, UN{}, FAST{});
+    for (; ss + HUN <= K0 - 2; ss += HUN) group(ss, UN{}, FAST{});
     for (; ss < K0 - 2; ++ss) group(ss, U1{}, FAST{});
     for (; ss < K0; ++ss) group(ss, U1{}, SAFE{});           // the last two steps: node 0 closes the tour; odd n: half 1 is one short
 }
 
-template <class S, class TT>
+template <int HUN, class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_lean_half(const S &s, const TT *t, const double *Eb, int n, int lane,
                                                            double &bd, int &bk) {
     // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39): rows i = 1..n-3, j = 3..n-1 (j >= i + 2 checked late)
@@ -1036,12 +1040,12 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean_half(const S &s, const TT 
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_HALF_UNROLL>;
+    using UN = std::integral_constant<int, HUN>;
     using U1 = std::integral_constant<int, 1>;
     using BODY = std::integral_constant<bool, false>;
     using TAIL = std::integral_constant<bool, true>;
     int ss = 0;
-    for (; ss + GLS_HALF_UNROLL <= J0 - 1; ss += GLS_HALF_UNROLL) group(ss, UN{}, BODY{});
+    for (; ss + HUN <= J0 - 1; ss += HUN) group(ss, UN{}, BODY{});
     for (; ss < J0 - 1; ++ss) group(ss, U1{}, BODY{});
     for (; ss < J0; ++ss) group(ss, U1{}, TAIL{});           // odd n - 3: half 1 is one step short
 }
@@ -1722,7 +1726,7 @@ struct PruneCtx {
     NlWords nlw; bool on;
 };
 
-template <class S, bool FI, int GP, bool CNT, bool PRUNE_OK, class TT, class TRC>
+template <class S, bool FI, int GP, bool CNT, int WPS, class TT, class TRC>
 __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, long long &xe, Stamps &st,
                                  TT *ppos, const PruneCtx &pc) {
@@ -1731,7 +1735,9 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // pruned descent scans (given neighbour lists): the 2-opt scan from n = 80 up, the relocate scan from n = 128 up (the
     // 4-slot instantiations) -- where each was measured faster (profiles/r03_experiments/README.md)
-    constexpr bool kCanPrune = !FI && S::kSymmetric && PRUNE_OK;
+    constexpr bool kCanPrune = !FI && S::kSymmetric && WPS <= GLS_PRUNE_MAX_WPS;
+    // steps per group of the half-wave scans: 4 on the 256-VGPR build (no scratch there), else GLS_HALF_UNROLL
+    constexpr int kHalfUnroll = WPS <= 2 ? 4 : GLS_HALF_UNROLL;
     constexpr bool kPruneRelocate = kCanPrune && GP == 4;
     const bool prune = kCanPrune && pc.on;
     double Lmax = 0.0;
@@ -1815,8 +1821,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 // a wavefront of its own
                 // (GP = register slots of the perturbation phase = the same 2 / 4, chosen by the launcher from n)
                 if (GLS_HALF_SCANS && GP == 1 && !lean && nwaves == 1 && n >= kHalfScanMinNodes && n <= kHalfScanMaxNodes) {
-                    if (op == 0) scan_two_opt_a2a_lean_half<S, TT>(s, t, Eb, n, lane, bd, bk);
-                    else         scan_relocate_a2a_lean_half<S, TT>(s, t, Ef, n, lane, bd, bk);
+                    if (op == 0) scan_two_opt_a2a_lean_half<kHalfUnroll, S, TT>(s, t, Eb, n, lane, bd, bk);
+                    else         scan_relocate_a2a_lean_half<kHalfUnroll, S, TT>(s, t, Ef, n, lane, bd, bk);
                     lean = true;
                 }
                 if (!lean && nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
@@ -1868,7 +1874,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 // TEAM: the perturbation phase runs on all wavefronts (team_perturbation above) -- for workgroups that own their CU.
 // CNT: also count the delta evaluations the pruned descent scans execute (GlsArgs::evals_exec; measurement builds, see there).
 template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM = false, bool CNT = false>
-__global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs A) {
+__global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
     const int n = A.n;
@@ -1975,7 +1981,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
         }
     }
     long long xe = 0;        // executed minus reference-equivalent evaluations of this wavefront's pruned scans (CNT builds)
-    local_search_dev<S, FI, GP, CNT, (WPS <= GLS_PRUNE_MAX_WPS)>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
+    local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
@@ -2130,7 +2136,7 @@ __global__ __launch_bounds__(WPS <= 4 ? 1024 : 512, WPS) void gls_kernel(GlsArgs
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI, GP, CNT, (WPS <= GLS_PRUNE_MAX_WPS)>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
+        local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -2405,6 +2411,12 @@ static hipError_t launch_gls_f(const GlsArgs &A, size_t lds, int threads, bool f
                              : launch_gls_t<S, false, WPS, TEAM>(A, lds, threads, stream);
 }
 
+// 256-VGPR instantiation (two waves per SIMD) of the one-slot kernel: single-wavefront workgroups, n = 8 .. 33, best improvement
+bool gls_wps2_supported(int store, int penalty_bits, int n, int threads, bool first_improvement) {
+    return GLS_WPS2 && GLS_HALF_SCANS && !first_improvement && threads == kWave && n >= kHalfScanMinNodes && n <= kHalfScanMaxNodes &&
+           penalty_bits == 32 && (store == GLS_STORE_COMPACT || store == GLS_STORE_TRI);
+}
+
 bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads) {
     // the team form exists for the 128-VGPR builds of the two symmetric stores with 32-bit counters, n <= 255; it caches the
     // utilities of the tour edges by position on wavefronts 0 .. ceil(n / 64) - 1, so the workgroup needs that many
@@ -2416,6 +2428,13 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                       hipStream_t stream) {
     if (team && !gls_team_supported(store, penalty_bits, wps, A.n, threads)) return hipErrorInvalidValue;
     size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
+#if GLS_WPS2
+    if (wps == 2) {          // single-wavefront workgroups on the 256-VGPR build (gls_wps2_supported)
+        if (!gls_wps2_supported(store, penalty_bits, A.n, threads, first_improvement) || team) return hipErrorInvalidValue;
+        if (store == GLS_STORE_COMPACT) return launch_gls_g<TriDGlobalP, false, 1, 2, false>(A, lds, threads, stream);
+        return launch_gls_g<TriStore<int32_t>, false, 1, 2, false>(A, lds, threads, stream);
+    }
+#endif
     if (store == GLS_STORE_COMPACT) {
         if (team) return launch_gls_f<TriDGlobalPF, 4, true>(A, lds, threads, first_improvement, stream);
         return wps == 8 ? launch_gls_f<TriDGlobalP, 8>(A, lds, threads, first_improvement, stream)

@@ -195,7 +195,8 @@ int gnngls_debug_set_penalty16_limit(int limit);
 int gnngls_debug_set_gls_threads(int threads);
 
 /* Register budget of the kernel instantiation gnngls_gls_run would launch for (n, B, penalty_bits), as resident wavefronts
- * per SIMD: 4 = the 128-VGPR builds (no scratch; every BASELINE.json shape runs on these), 6 / 8 = the 80- / 64-VGPR
+ * per SIMD: 4 = the 128-VGPR builds (no scratch), 2 = the 256-VGPR build of the single-wavefront kernel (n = 8 .. 33, at
+ * most 2048 instances: TSP20 x 1000; no scratch) -- every BASELINE.json shape runs on these two --, 6 / 8 = the 80- / 64-VGPR
  * builds (56-148 B of scratch per lane) that only batches of small instances beyond 16 workgroups per CU select
  * (e.g. TSP20 x 5000).  0 = bad argument. */
 int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits);

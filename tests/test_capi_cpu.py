@@ -114,15 +114,19 @@ def test_gls_store_selection(lib):
 
 
 def test_baseline_shapes_run_on_the_scratch_free_instantiations(lib):
-    """Every BASELINE.json shape (and the rounds a larger test set is cut into) selects a 128-VGPR build of the search kernel
-    (4 resident wavefronts per SIMD; zero scratch: profiles/r03_kernel_resources.txt) and stays fully resident; the 80- /
-    64-VGPR builds (scratch) are only chosen by batches of small instances beyond 16 workgroups per CU."""
+    """Every BASELINE.json shape (and the rounds a larger test set is cut into) selects a scratch-free build of the search
+    kernel -- the 128-VGPR one (4 resident wavefronts per SIMD; profiles/r03_kernel_resources.txt), or for single-wavefront
+    workgroups that fit two per SIMD (TSP20 x 1000) the 256-VGPR one -- and stays fully resident; the 80- / 64-VGPR builds
+    (scratch) are only chosen by batches of small instances beyond 16 workgroups per CU."""
     from gnngls_amd import ops
     for n, B in ((20, 1000), (50, 128), (50, 2048), (100, 1024), (100, 625), (100, 1250), (200, 256)):
         c = ops.gls_describe_config(n, B)
-        assert c["waves_per_simd"] == 4, (n, B, c)
+        assert c["waves_per_simd"] == (2 if n == 20 else 4), (n, B, c)
         assert c["per_cu"] * 256 >= min(B, ops.gls_resident_capacity(n)), (n, B, c)
+    # the 256-VGPR build: single-wavefront workgroups (n = 8 .. 33), at most 2 per SIMD = 2048 instances
+    assert ops.gls_describe_config(30, 2048)["waves_per_simd"] == 2 and ops.gls_describe_config(30, 2049)["waves_per_simd"] == 4
+    assert ops.gls_describe_config(7, 100)["waves_per_simd"] == 4 and ops.gls_describe_config(34, 100)["waves_per_simd"] == 4
     spilling = [(n, B) for n in (10, 20, 30, 50, 100, 150, 200) for B in (64, 1024, 1536, 3000, 5000, 8192)
-                if ops.gls_describe_config(n, B)["waves_per_simd"] != 4]
+                if ops.gls_describe_config(n, B)["waves_per_simd"] not in (2, 4)]
     assert spilling and all(n <= 50 and B > 1024 for n, B in spilling), spilling
     assert ops.gls_describe_config(20, 5000)["waves_per_simd"] in (6, 8)
