@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--oracle_instances", type=int, default=-1, help="-1 = one per host core")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--start_block", type=int, default=0, help="first block to compute (with --merge: the earlier blocks of that file are kept)")
+    ap.add_argument("--merge", default=None, help="existing best-known file of the same (n, seed): its blocks are kept, new blocks are "
+                                                  "added, a block present in both keeps the elementwise minimum")
     args = ap.parse_args()
 
     from gnngls_amd import ops, pipeline
@@ -52,10 +55,10 @@ def main():
     scalers = None
     out, log = {}, []
     t_all = time.time()
-    for k in range(args.blocks):
+    if scalers is None:                                                                   # as bench.py: fitted on block 0
+        scalers = pipeline.Scalers.fit_weights(torch.from_numpy(random_instances(np.random.default_rng(args.seed), BLOCK, n)[0]).cuda())
+    for k in range(args.start_block, args.blocks):
         D_host, _ = random_instances(np.random.default_rng(args.seed + 1000 * k), BLOCK, n)
-        if scalers is None:
-            scalers = pipeline.Scalers.fit_weights(torch.from_numpy(D_host).cuda())      # as bench.py: fitted on block 0
         D = torch.from_numpy(D_host[:args.count]).cuda()
         runs = [(("regret_pred",), 20), (("weight",), 20)]
         if k == 0:
@@ -97,6 +100,16 @@ def main():
     how = (f"min over GPU guided_local_search runs of {args.seconds:g} s per instance with guides regret_pred and weight "
            f"(perturbation_moves 20; block 0 also weight/30, [weight,regret_pred]/20 and a {args.seconds:g} s CPU-oracle run on "
            f"one instance per host core), lengths recomputed by tour_cost; scripts/make_best_known.py")
+    if args.merge:
+        z = np.load(args.merge, allow_pickle=False)
+        assert int(z["n"]) == n and int(z["seed"]) == args.seed, "--merge: another instance set"
+        for key in z.files:
+            if key.startswith("block"):
+                out[key] = np.fmin(z[key], out[key]) if key in out else z[key]           # fmin: NaN = not covered
+            elif key.startswith("winner") and key not in out:
+                out[key] = z[key]
+        log = json.loads(str(z["log"])) + log
+        how = str(z["how"]) + f"; blocks {args.start_block}..{args.blocks - 1} (first {args.count} instances each) added later the same way"
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     np.savez_compressed(args.out, n=n, seed=args.seed, how=np.array(how), log=np.array(json.dumps(log)), **out)
     print(f"wrote {args.out} ({args.blocks} blocks, {time.time() - t_all:.0f} s)")

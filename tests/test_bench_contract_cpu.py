@@ -211,3 +211,18 @@ def test_shard_and_round_plan_of_an_eight_rank_launch(monkeypatch):
     assert b.shard_plan(0, 1024, 8, 7) == (8192, 7168, 8192, None) and b.round_plan(1024, 0, 1024) == (1024, 1, 1024)
     # a device that cannot keep the instance size resident (capacity query 0) still gets a plan
     assert b.round_plan(100, 0, 0) == (64, 2, 50) and b.round_plan(0, 0, 1024) == (1024, 0, 1024)
+
+
+def test_best_known_files_cover_every_rank_of_an_eight_gpu_launch():
+    """The gap of an N-rank line needs best-known lengths for every rank's instances: weak scaling gives rank r the first
+    `batch` instances of block r -- TSP100: blocks 0-9 complete (also configs[3]'s 10,000-instance test set), TSP200: the first
+    256 instances of blocks 0-7 (configs[4] on 8 GPUs), TSP50: block 0."""
+    b = bench_module()
+    for r in range(8):
+        bk, how = b.load_best_known(None, 100, 2024, r * 1024, r * 1024 + 1024)
+        assert bk is not None and np.isfinite(bk).all() and (bk > 5).all(), (r, how)
+        bk, how = b.load_best_known(None, 200, 2024, r * 1024, r * 1024 + 256)
+        assert bk is not None and np.isfinite(bk).all() and (bk > 8).all(), (r, how)
+    assert b.load_best_known(None, 100, 2024, 0, 10000)[0] is not None
+    assert b.load_best_known(None, 200, 2024, 0, 257)[0] is None                 # beyond the covered part of a block: no silent gaps
+    assert b.load_best_known(None, 50, 2024, 0, 1024)[0] is not None
