@@ -45,7 +45,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 PEAK_LDS_GBS = 150000.0          # MI355X_MICROARCH.md: aggregate ds_read_b64 rate, every CU streaming
 BLOCK = 1024                     # instances per seeded block
-N_SIMDS, N_CUS = 1024, 256       # MI355X: 256 CUs x 4 SIMDs
+N_SIMDS = 1024                   # MI355X: 256 CUs x 4 SIMDs
 GAP_GRID_S = (0.1, 0.3, 1.0, 3.0)   # search seconds at which the gap-versus-budget record is read (+ the end of the budget)
 IMP_CAP = 256                    # improvement-trace entries kept per instance (a 10 s TSP100 search improves its best a few dozen times)
 ISO_ROUNDS = 10                  # device loads that share ONE time limit in the iso-quality pass
