@@ -134,7 +134,7 @@ struct TriStore {
     static constexpr int kScanUnroll = 1;        // 80-VGPR budget: no room for batched evaluations
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
-        return ((hi * (hi - 1)) >> 1) + lo;
+        return (__mul24(hi, hi - 1) >> 1) + lo;              // (nodes < 2^23: the full-rate 24-bit multiply)
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     __device__ __forceinline__ int pen(int a, int b) const { return (int)p[idx(a, b)]; }
@@ -142,6 +142,12 @@ struct TriStore {
     __device__ __forceinline__ static int idx2(int a, int a2, int c, int c2) { return a > c ? a2 + c : c2 + a; }
     __device__ __forceinline__ double dist_at(int q) const { return d[q]; }
     __device__ __forceinline__ int pen_at(int q) const { return (int)p[q]; }
+    // byte-offset forms (block form of the serial perturbation phase; 32-bit counters): off4 = 4 x packed index
+    __device__ __forceinline__ double dist_at_byte(int off8) const { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(d) + off8); }
+    __device__ __forceinline__ int pen_at_byte(int off4) const { return (int)*reinterpret_cast<const PT *>(reinterpret_cast<const char *>(p) + off4); }
+    __device__ __forceinline__ void pen_store_byte_if(unsigned long long lanes, int off4, int v) const {
+        if ((lanes >> (threadIdx.x & 63)) & 1ull) *reinterpret_cast<PT *>(reinterpret_cast<char *>(p) + off4) = (PT)v;
+    }
     int limit;         // largest representable count (65535 for 16-bit counters; lowered only by the test hook)
     // the caller already holds the current count (register-cached): store old + 1 without reading the counter back
     __device__ __forceinline__ bool pen_set(int a, int b, int old_count) const {     // true = counter overflow
@@ -181,7 +187,7 @@ struct TriDGlobalP {
     static constexpr int kScanUnroll = 1;        // measured: 2-deep batching costs more in spills than it hides (8.6k vs 10.0k)
     __device__ __forceinline__ static int idx(int a, int b) {
         int hi = a > b ? a : b, lo = a > b ? b : a;
-        return ((hi * (hi - 1)) >> 1) + lo;
+        return (__mul24(hi, hi - 1) >> 1) + lo;              // (n <= 255: the full-rate 24-bit multiply)
     }
     __device__ __forceinline__ double dist(int a, int b) const { return d[idx(a, b)]; }
     // index with the triangular row offsets precomputed: a2 = a(a-1)/2 (per lane), c2 = c(c-1)/2 (wave-uniform, SALU)
@@ -197,6 +203,22 @@ struct TriDGlobalP {
     __device__ __forceinline__ void pen_store(int q, int v) const { p[q] = v; }
 #endif
     __device__ __forceinline__ int pen(int a, int b) const { return pen_at(idx(a, b)); }
+    // byte-offset forms (block form of the serial perturbation phase): off4 = 4 x packed index
+    __device__ __forceinline__ double dist_at_byte(int off8) const { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(d) + off8); }
+#if GLS_PEN_BUFFER
+    __device__ __forceinline__ int pen_at_byte(int off4) const { return __builtin_amdgcn_raw_buffer_load_b32(prs, off4, 0, 0); }
+    // the lanes of `lanes` store, the others aim past the end of the buffer: the range check drops their store -- no branch
+    __device__ __forceinline__ void pen_store_byte_if(unsigned long long lanes, int off4, int v) const {
+        int o;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(0x7ffffffc), "v"(off4), "s"(lanes));
+        __builtin_amdgcn_raw_buffer_store_b32(v, prs, o, 0, 0);
+    }
+#else
+    __device__ __forceinline__ int pen_at_byte(int off4) const { return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(p) + off4); }
+    __device__ __forceinline__ void pen_store_byte_if(unsigned long long lanes, int off4, int v) const {
+        if ((lanes >> (threadIdx.x & 63)) & 1ull) *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(p) + off4) = v;
+    }
+#endif
     __device__ __forceinline__ bool pen_inc(int a, int b) const {
         const int q = idx(a, b);
         pen_store(q, pen_at(q) + 1);
@@ -216,6 +238,11 @@ struct TriDGlobalP {
 // stored (two stores per penalty step, by the one lane that owns the edge).
 struct TriDGlobalPF : TriDGlobalP {
     int n;
+    // the packed-triangle accessors of the base (its buffer descriptor is not bound here) must not be reached through this store
+    int pen_at(int) const = delete;
+    void pen_store(int, int) const = delete;
+    int pen_at_byte(int) const = delete;
+    void pen_store_byte_if(unsigned long long, int, int) const = delete;
     __device__ __forceinline__ int pen(int a, int b) const { return p[a * n + b]; }
     // matrix cell r = row * n + column >= 0: base (scalar registers) + an unsigned 32-bit byte offset -- the load takes the
     // offset register as it is; an int index costs a sign extension and a 64-bit add per load
@@ -1866,6 +1893,342 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Edge form of the serial perturbation phase (algorithms.py:150-185), symmetric stores, best improvement
+// ---------------------------------------------------------------------------------------------
+// A penalty step is a dependent chain on ONE wavefront: arg-max, counter store, then up to four guided one-to-all scans
+// (two endpoints x {two_opt_o2a, relocate_o2a}, algorithms.py:167-174) with a move after any of them.  What that chain
+// costs was measured instruction by instruction (scripts/isa_probe/latency_probe.hip, profiles/r05_isa/): one wavefront
+// issues ANY instruction -- fp64 or integer, vector or scalar -- every ~4.3 cycles at best, an exec-masked `if` (v_cmp,
+// s_and_saveexec, s_cbranch_execz, s_or) costs ~45 cycles even when nothing is skipped, a scalar branch 15-35, a
+// v_cndmask on VCC 8-17 (on another scalar pair: 4.3), a DPP reduction step 12, an fp64 division 68, an LDS round trip
+// ~60 and a counter load from L2 270 and more.  The scan-by-scan form above pays, per 64-lane pass, a tour read, three or
+// four packed indices with their loads and four exec-masked branches: ~650 cycles, eight passes per step at n = 100.  Here
+//   * lane l keeps, per slot q, tour EDGE p = l + 64 q in registers: its nodes (u, v) = (t[p], t[p+1]) with their packed
+//     row offsets, its counter, distance and guide value (TourEdges) -- the arg-max's operands and the tour-edge terms of
+//     every scan; the tour itself is only WRITTEN to LDS (for the descent, and as the source of the next move);
+//   * a scan is enumerated by the edge k = p the lane owns (two_opt_o2a: j = k + 1; relocate_o2a: target edge k, i.e.
+//     j = k for i < j and j = k + 1 for i > j, operators.py:91-96), so its per-lane terms are G[a, v], G[b, u] (2-opt) and
+//     G[a, u], G[a, v] (relocate) with a = t[i], b = t[i-1] wave-uniform: TWO guided values per lane and slot instead of
+//     three or four, all slots of the scan in flight at once; every other term (the lane's own edge, the scan's own edges)
+//     comes from the registers (v_readlane for the uniform ones); G[x,y] = D[x,y] + k P[x,y], product rounded first [exact];
+//   * conditions live in scalar register pairs (v_cmp ... e64 / lane masks computed once per phase), selects take them
+//     from there, and a scan none of whose lanes has a negative delta -- most scans -- costs one compare per slot and one
+//     scalar branch: np.isclose, the strict-< bookkeeping and the wave reduction only run behind that test;
+//   * the move is applied from LDS to registers: new (u, v) = told[src(p)], told[src(p + 1)], tnew[p] = u is a store nobody
+//     waits for.
+// Same operands, same operand order, same keys, same order of consumption as the scan-by-scan form: bit-exact.  Measured and
+// dropped: evaluating several pending scans of a step at once, speculatively, in the reference's order of consumption (blocks
+// of two to four scans chosen by running acceptance estimates): bit-exact and 0.5-3 % slower than one scan at a time
+// (profiles/r05_experiments/).
+#ifndef GLS_EDGE_PERTURB
+#define GLS_EDGE_PERTURB 1           // 0: the scan-by-scan serial form everywhere (A/B builds)
+#endif
+
+typedef unsigned long long lanemask_t;
+// lane-wise m ? a : b with the condition in a scalar register pair (v_cndmask_b32 e64: 4.3 cycles; on VCC the same select
+// measures 8-17)
+__device__ __forceinline__ int sel_b32(lanemask_t m, int a, int b) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double sel_f64(lanemask_t m, double a, double b) {
+    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const int lo = sel_b32(m, (int)ab, (int)bb), hi = sel_b32(m, (int)(ab >> 32), (int)(bb >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+template <int GP>
+struct TourEdges {
+    int u[GP], v[GP];                // nodes of tour edge p = lane + 64 q (lanes with p >= n hold edge 0: valid nodes, results masked)
+    int ur[GP], vr[GP];              // 4 u (u - 1) / 2, 4 v (v - 1) / 2: byte offset of the node's row in a packed int32 triangle
+    int pq[GP];                      // penalty counter of the edge
+    double gq[GP];                   // utility numerator G.edges[e][guide] (algorithms.py:155)
+    double de[GP];                   // D[u, v]
+};
+
+// value of a per-edge register at tour edge p (wave-uniform p; slot p >> 6, lane p & 63: v_readlane takes the lane modulo 64)
+template <int GP>
+__device__ __forceinline__ int edge_bcast(const int (&x)[GP], int p) {
+    int r[GP];
+#pragma unroll
+    for (int q = 0; q < GP; ++q) r[q] = __builtin_amdgcn_readlane(x[q], p);      // all slots, then scalar selects: no branch
+    int v = r[0];
+#pragma unroll
+    for (int q = 1; q < GP; ++q) v = p >= q * kWave ? r[q] : v;
+    return v;
+}
+template <int GP>
+__device__ __forceinline__ double edge_bcast_f64(const double (&x)[GP], int p) {
+    int lo[GP], hi[GP];
+#pragma unroll
+    for (int q = 0; q < GP; ++q) { const long long b = __double_as_longlong(x[q]); lo[q] = (int)b; hi[q] = (int)(b >> 32); }
+    const int l = edge_bcast<GP>(lo, p), h = edge_bcast<GP>(hi, p);
+    return __longlong_as_double(((long long)h << 32) | (unsigned)l);
+}
+
+// byte offset of the pair {x, y} in a packed int32 triangle, x wave-uniform (xr = 4 x(x-1)/2 on the scalar unit), y per lane
+// with its row offset yr: 4 vector instructions; the packed fp64 triangle is at twice that offset
+__device__ __forceinline__ int pair_offset(int x, int xr, int y, int yr) {
+    const lanemask_t gt = __builtin_amdgcn_ballot_w64(y > x);
+    return sel_b32(gt, yr + 4 * x, xr + 4 * y);
+}
+// counter and distance of a node pair, in flight
+struct PairLoad { int p; double d; };
+template <class S>
+__device__ __forceinline__ PairLoad pair_issue(const S &s, int off4) {
+    PairLoad g;
+    g.p = s.pen_at_byte(off4);
+    g.d = s.dist_at_byte(2 * off4);
+    return g;
+}
+__device__ __forceinline__ double guided(double k, const PairLoad &g) { return g.d + k * (double)g.p; }   // [exact] algorithms.py:164
+__device__ __forceinline__ void pin(PairLoad &g) { asm volatile("" : "+v"(g.p), "+v"(g.d)); }
+
+// (counter, distance, guide) of every tour edge, and the row offsets of its nodes, from E.u / E.v
+template <class S, int GP>
+__device__ __forceinline__ void edges_fetch(const S &s, TourEdges<GP> &E, const double *guide, int n) {
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        const int u = E.u[q], v = E.v[q];
+        E.gq[q] = guide[(unsigned)(u * n + v)];
+        E.ur[q] = 2 * __mul24(u, u - 1); E.vr[q] = 2 * __mul24(v, v - 1);
+        const int off = sel_b32(__builtin_amdgcn_ballot_w64(v > u), E.vr[q] + 4 * u, E.ur[q] + 4 * v);
+        E.pq[q] = s.pen_at_byte(off);
+        E.de[q] = s.dist_at_byte(2 * off);
+    }
+}
+template <class S, int GP, class TT>
+__device__ __forceinline__ void edges_load(const S &s, TourEdges<GP> &E, const TT *t, const double *guide, int n, int lane) {
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        const int p = lane + q * kWave, pc = p < n ? p : 0;
+        E.u[q] = t[pc]; E.v[q] = t[pc + 1];
+    }
+    edges_fetch(s, E, guide, n);
+}
+// the move (op, i, j) applied: new edges straight from the old tour (operators.py:6-11, 76-80), new tour written behind.
+// (lanes past the tour rewrite position 0 with the depot; position n always holds the depot in both tour arrays)
+template <class S, int GP, class TT>
+__device__ __forceinline__ void edges_move(const S &s, TourEdges<GP> &E, const TT *told, TT *tnew, const double *guide,
+                                           int n, int op, int i, int j, int lane) {
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        const int p = lane + q * kWave, pc = p < n ? p : 0;
+        const int u = told[move_src(op, pc, i, j)], v = told[move_src(op, pc + 1, i, j)];
+        E.u[q] = u; E.v[q] = v;
+        tnew[pc] = (TT)u;
+    }
+    edges_fetch(s, E, guide, n);
+}
+
+// key image of a utility for "first maximum wins": larger value -> smaller unsigned 64-bit key (-0.0 and +0.0 share one)
+__device__ __forceinline__ void argmax_key(double v, unsigned &hi, unsigned &lo) {
+    v = v + 0.0;                                             // -0.0 -> +0.0, every other value unchanged
+    const long long b = __double_as_longlong(v);
+    const int h = (int)(b >> 32), t = ~(h >> 31);            // t = all ones for v >= 0
+    hi = (unsigned)h ^ ((unsigned)t >> 1);
+    lo = (unsigned)b ^ (unsigned)t;
+}
+// position of the first maximum of the tour edges' utilities (algorithms.py:153-159): util[q] = the lane's utility of edge
+// lane + 64 q, nm0[q] = lanes whose edge exists.  Straight-line: per-slot selects on scalar masks, one DPP reduction over the
+// high words of the key image, the low words and positions only on a tie.  The maximum itself is not needed.
+template <int GP>
+__device__ __forceinline__ int argmax_first_pos(const double (&util)[GP], const lanemask_t (&nm0)[GP], int lane) {
+    double bu = util[0];
+    int pos = lane;
+#pragma unroll
+    for (int q = 1; q < GP; ++q) {                           // (a lane's edges exist in ascending slots: strict > keeps the first)
+        const lanemask_t up = nm0[q] & __builtin_amdgcn_ballot_w64(util[q] > bu);
+        bu = sel_f64(up, util[q], bu);
+        pos = sel_b32(up, lane + q * kWave, pos);
+    }
+    unsigned hi, lo;
+    argmax_key(bu, hi, lo);
+    hi = (unsigned)sel_b32(nm0[0], (int)hi, -1);             // (n < 64: lanes without an edge lose)
+    const unsigned mhi = wave_umin(hi);
+    const lanemask_t tie = __builtin_amdgcn_ballot_w64(hi == mhi);
+    if ((tie & (tie - 1)) == 0ull)                           // one lane holds the smallest high word: the usual case
+        return __builtin_amdgcn_readlane(pos, __ffsll((long long)tie) - 1);
+    const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
+    return (int)wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
+}
+
+// One guided one-to-all scan at tour index i on the tour held by E: RELOC = false two_opt_o2a, true relocate_o2a.
+// ok[q] = the lanes of slot q with a valid move, delta[q] their deltas; returns the lanes (any slot) with a negative one.
+template <bool RELOC, class S, int GP>
+__device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, const TourEdges<GP> &E, const int lane, const int i,
+                                                const lanemask_t (&nm)[GP], double (&delta)[GP], lanemask_t (&ok)[GP]) {
+    const int na = edge_bcast<GP>(E.u, i), nb = edge_bcast<GP>(E.u, i - 1);       // a = t[i], b = t[i-1]
+    const int nar = 2 * na * (na - 1), nbr = 2 * nb * (nb - 1);
+    PairLoad x0[GP], x1[GP], xac;
+    if (RELOC) {                                             // G[t[i-1], t[i+1]]: a wave-uniform pair
+        const int nc = edge_bcast<GP>(E.v, i);
+        xac = pair_issue(s, nc > nb ? 2 * nc * (nc - 1) + 4 * nb : nbr + 4 * nc);
+    }
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        x0[q] = pair_issue(s, pair_offset(na, nar, E.v[q], E.vr[q]));                             // G[t[i], t[k+1]]
+        x1[q] = RELOC ? pair_issue(s, pair_offset(na, nar, E.u[q], E.ur[q]))                      // G[t[i], t[k]]
+                      : pair_issue(s, pair_offset(nb, nbr, E.u[q], E.ur[q]));                     // G[t[i-1], t[k]]
+    }
+    // every load of the scan in flight before the first is consumed (cf. scan_two_opt_o2a_guided_rm)
+#pragma unroll
+    for (int q = 0; q < GP; ++q) { pin(x0[q]); pin(x1[q]); }
+    if (RELOC) pin(xac);
+    double ge[GP];                                           // guided length of the lane's own edges
+#pragma unroll
+    for (int q = 0; q < GP; ++q) ge[q] = E.de[q] + k * (double)E.pq[q];
+    const double gab = edge_bcast_f64<GP>(ge, i - 1);        // G[t[i-1], t[i]]
+    double base = 0.0;
+    if (RELOC) {
+        const double gbc = edge_bcast_f64<GP>(ge, i);        // G[t[i], t[i+1]]
+        base = -gab;                                         // operators.py:97-99, left to right
+        base = base - gbc;
+        base = base + guided(k, xac);
+    }
+    lanemask_t neg = 0ull;
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        const int kk = lane + q * kWave;
+        const double gav = guided(k, x0[q]), gxu = guided(k, x1[q]);
+        double d;
+        if (!RELOC) {
+            // two_opt_o2a (operators.py:53-73), j = k + 1: c = t[j] = v, d = t[j-1] = u; j > i: ((G[a,c] + G[b,d]) - G[a,b]) - G[c,d];
+            // j < i (operators.py:17-18 swap): the same sum, then G[c,d] of the lane's edge first, the scan's edge last
+            const lanemask_t lt = __builtin_amdgcn_ballot_w64(kk >= i);
+            d = gav + gxu;
+            d = d - sel_f64(lt, gab, ge[q]);
+            d = d - sel_f64(lt, ge[q], gab);
+            // j = 1 .. n-1, |i - j| >= 2 (operators.py:59-62): k <= n-2, k not in {i-2, i-1, i}
+            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 2) > 2u);
+        } else {
+            // relocate_o2a (operators.py:106-126) by target edge k = (d, e) = (u, v): ((base - G[d,e]) + G[d,b]) + G[b,e], b = t[i];
+            // j = k for i < j, j = k + 1 for i > j (operators.py:91-96); j != i: k not in {i-1, i}
+            d = base - ge[q];
+            d = d + gxu;
+            d = d + gav;
+            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 1) > 1u);
+        }
+        delta[q] = d;
+        neg |= ok[q] & __builtin_amdgcn_ballot_w64(d < 0.0);
+    }
+    return neg;
+}
+
+template <class S, int GP, bool TR, class TT, class TRC>
+__device__ __forceinline__ void serial_perturbation_edges(const S &s, const double k, TT *&t, TT *&t2, double *Ef, double *Eb,
+                                                          const int n, const double *guide, const GlsArgs &A,
+                                                          const long long t_start, double &cur_cost, TRC &tr,
+                                                          long long &evals, int &status, Stamps &st) {
+    static_assert(S::kSymmetric && sizeof(typename S::pen_t) == 4, "edge form: symmetric stores with 32-bit counters");
+    constexpr bool eager_cost = TR;
+    const int lane = threadIdx.x & (kWave - 1);
+    lanemask_t nm0[GP], nm2[GP];                             // lanes whose edge k = lane + 64 q is <= n-1 / <= n-2
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        nm0[q] = __builtin_amdgcn_ballot_w64(lane + q * kWave < n);
+        nm2[q] = __builtin_amdgcn_ballot_w64(lane + q * kWave < n - 1);
+    }
+    if (lane == 0) { t2[0] = (TT)t[0]; t2[n] = (TT)t[n]; }   // positions 0 and n hold the depot in both tour arrays
+    TourEdges<GP> E;
+    edges_load(s, E, t, guide, n, lane);
+    bool any_moved = false;
+    int moves = 0, scans_to = 0, scans_re = 0;               // one-to-all scans executed (evaluation count, booked at the end)
+    long long steps = 0;
+    const int max_moves = A.perturbation_moves;
+    while (moves < max_moves) {
+        // ---- arg-max utility over the tour edges, first maximum wins (algorithms.py:153-159); only its position is used ----
+        double util[GP];
+#pragma unroll
+        for (int q = 0; q < GP; ++q) util[q] = E.gq[q] / (1.0 + (double)E.pq[q]);     // lanes past the tour hold edge 0: masked
+        const int bp = argmax_first_pos<GP>(util, nm0, lane);
+        STAMP_END(0);
+        const int eu = edge_bcast<GP>(E.u, bp), ev = edge_bcast<GP>(E.v, bp);
+        // algorithms.py:161: the lane that holds edge bp stores count + 1 itself (no load -> add -> store round trip)
+        {
+            int cnt = 0;
+            lanemask_t own = 0ull;
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const lanemask_t o = __builtin_amdgcn_ballot_w64(lane + q * kWave == bp);
+                E.pq[q] += sel_b32(o, 1, 0);
+                cnt = sel_b32(o, E.pq[q], cnt);
+                own |= o;
+            }
+            s.pen_store_byte_if(own, eu > ev ? 2 * eu * (eu - 1) + 4 * ev : 2 * ev * (ev - 1) + 4 * eu, cnt);
+        }
+        int i = bp;                                          // algorithms.py:169: the edge was read at positions bp, bp + 1
+        bool moved_this_step = false;
+#pragma unroll 1
+        for (int sc = eu == 0 ? 2 : 0; sc < (ev == 0 ? 2 : 4); ++sc) {      // scan = 2 endpoint + operator; algorithms.py:167-171
+            if (sc == 2) {                                   // endpoint 1: cur_tour.index(ev), searched only after a move
+                i = bp + 1;
+                if (moved_this_step) {
+#pragma unroll
+                    for (int q = GP - 1; q >= 0; --q) {
+                        const lanemask_t m = nm0[q] & __builtin_amdgcn_ballot_w64(E.u[q] == ev);
+                        if (m) i = q * kWave + __ffsll((long long)m) - 1;
+                    }
+                }
+            }
+            double delta[GP];
+            lanemask_t ok[GP];
+            const bool reloc = (sc & 1) != 0;
+            const lanemask_t neg = reloc ? eval_scan<true, S, GP>(s, k, E, lane, i, nm0, delta, ok)
+                                         : eval_scan<false, S, GP>(s, k, E, lane, i, nm2, delta, ok);
+            if (reloc) scans_re += 1; else scans_to += 1;
+            STAMP_END(1);
+            if (neg == 0ull) continue;                       // no negative delta: no candidate (most scans)
+            // np.isclose evaluated literally; the keys of a lane ascend with its slots, so a strict < keeps the lane's first
+            // minimum (operators.py:65,118)
+            double bd = 0.0; int bk = kNoKey;
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const double d = delta[q];
+                const int kk = lane + q * kWave;
+                const int key = reloc ? (kk >= i + 1 ? kk : kk + 1) : kk + 1;
+                const lanemask_t take = ok[q] & __builtin_amdgcn_ballot_w64(d < bd) & ~__builtin_amdgcn_ballot_w64(close_to_zero(d));
+                bd = sel_f64(take, d, bd);
+                bk = sel_b32(take, key, bk);
+            }
+            if (__builtin_amdgcn_ballot_w64(bk != kNoKey) == 0ull) { STAMP_END(2); continue; }
+            wave_reduce_best<false>(bd, bk);
+            bk = __builtin_amdgcn_readfirstlane(bk);
+            STAMP_END(2);
+            edges_move(s, E, t, t2, guide, n, sc & 1, i, bk, lane);          // algorithms.py:175-177
+            { TT *x = t; t = t2; t2 = x; }
+            any_moved = true; moved_this_step = true;
+            moves += 1;                                      // algorithms.py:185
+            if (eager_cost) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q) if (lane + q * kWave < n) Ef[lane + q * kWave + 1] = E.de[q];
+                wave_sync();
+                cur_cost = tour_cost_from_edges(Ef, n);      // algorithms.py:176
+                if (lane == 0) tr.push(cur_cost);
+            }
+            STAMP_END(3);
+        }
+        steps++;
+        STAMP_COUNT(6);
+        if ((steps & 63) == 0) {
+            const long long el = wall_clock64() - t_start;
+            if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
+        }
+    }
+    if (lane == 0) {
+        evals += (long long)scans_to * (n - 3) + (long long)scans_re * (n - 2);
+        if (!eager_cost) tr.len += moves;                    // moves counted, costs deferred
+    }
+    if (any_moved && !eager_cost) {
+        wave_sync();
+        build_edges(s, t, Ef, Eb, n, lane, kWave);
+        wave_sync();
+        cur_cost = tour_cost_from_edges(Ef, n);
+    }
+}
+
 // launch bounds: 8-wave workgroups, 6 waves per SIMD for the LDS-resident variants (3 workgroups per
 // CU at n=100 need <= 80 VGPRs), 4 for the global-memory fallback.
 // WPS = resident wavefronts per SIMD the kernel is compiled for = its register budget (512 / WPS VGPRs).  The compact store
@@ -1879,7 +2242,14 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
     const int b = blockIdx.x;
     const int n = A.n;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    // the edge form of the serial perturbation phase: best improvement, 32-bit counters, the 128-VGPR (and wider) builds
+    constexpr bool kEdgeForm = GLS_EDGE_PERTURB && S::kSymmetric && !FI && !TEAM && sizeof(typename S::pen_t) == 4 && WPS <= 4;
+    // wave-uniform by construction; as a SCALAR it keeps `if (wave == 0)` -- the serial perturbation phase -- a scalar branch and
+    // what the phase modifies (tour pointers, cost, counters) out of the exec-masked phis of a divergent one.  Measured
+    // (profiles/r05_experiments/): +1 % for the team form, needed by the edge form, -4 % for the scan-by-scan form (whose code
+    // was tuned around the vector form of `wave`), which therefore keeps it
+    const int lane = tid & (kWave - 1);
+    const int wave = (TEAM || kEdgeForm) ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const size_t nn = (size_t)n * n;
     const double *Dg = A.D + (size_t)b * nn;
 
@@ -1988,7 +2358,6 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
     __syncthreads();
 
     long long iter_i = 0;
-
     for (;;) {
         // ---- loop condition (algorithms.py:146) ----
         if (tid == 0) {
@@ -2014,6 +2383,9 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
             // the serial chain of this instance competes for issue slots with the (latency-tolerant) descent
             // waves of the other resident workgroups on the same SIMD: give it priority while it runs
             __builtin_amdgcn_s_setprio(GLS_PERTURB_PRIO);
+            if constexpr (kEdgeForm) {
+                serial_perturbation_edges<S, GP, TR>(s, k, t, t2, Ef, Eb, n, guide, A, t_start, cur_cost, tr, evals, status, st);
+            } else {
             bool any_moved = false;
             int moves = 0;
             long long steps = 0;
@@ -2120,6 +2492,7 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
                 build_edges(s, t, Ef, Eb, n, lane, kWave);
                 wave_sync();
                 cur_cost = tour_cost_from_edges(Ef, n);
+            }
             }
             // tour buffers may have been swapped an odd number of times: publish which one is current
             if (lane == 0) { ctl->cost = cur_cost; ctl->pad = (int)((unsigned char *)t - smem); }
@@ -2399,6 +2772,9 @@ static hipError_t launch_gls_t(const GlsArgs &A, size_t lds, int threads, hipStr
     if constexpr (!FI && !TEAM && WPS == 4 && S::kSymmetric && sizeof(typename S::pen_t) == 4) {
         if (GLS_HALF_SCANS && A.n >= kHalfScanMinNodes && A.n <= kHalfScanMaxNodes && threads == kWave)
             return launch_gls_g<S, FI, 1, WPS, TEAM>(A, lds, threads, stream);
+        // the edge form of the serial perturbation phase evaluates every register slot of a lane: n <= 63 (tour positions
+        // 0 .. n in one slot) runs on the one-slot instantiation whatever the workgroup shape (TSP50)
+        if (GLS_EDGE_PERTURB && A.n <= kWave - 1) return launch_gls_g<S, FI, 1, WPS, TEAM>(A, lds, threads, stream);
     }
     // register-cached guide/penalty values of the tour edges: 2 passes of 64 lanes cover positions 0..n for n <= 127
     if (A.n + 1 <= 2 * kWave) return launch_gls_g<S, FI, 2, WPS, TEAM>(A, lds, threads, stream);
@@ -2428,6 +2804,11 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                       hipStream_t stream) {
     if (team && !gls_team_supported(store, penalty_bits, wps, A.n, threads)) return hipErrorInvalidValue;
     size_t lds = gls_lds_bytes(A.n, store, penalty_bits, team);
+#ifdef GLS_DEV_ONLY_HEADLINE
+    // development builds (ISA inspection, fast compiles): only the instantiation the TSP100 x 1024 headline runs on
+    (void)store; (void)penalty_bits; (void)wps; (void)first_improvement;
+    return launch_gls_k<TriDGlobalP, false, 2, false, 4, false>(A, lds, threads, stream);
+#else
 #if GLS_WPS2
     if (wps == 2) {          // single-wavefront workgroups on the 256-VGPR build (gls_wps2_supported)
         if (!gls_wps2_supported(store, penalty_bits, A.n, threads, first_improvement) || team) return hipErrorInvalidValue;
@@ -2448,6 +2829,7 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
                         : launch_gls_f<TriStore<int32_t>, TriStore<int32_t>::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
     }
     return launch_gls_f<GlobalStore, GlobalStore::kWavesPerSimd>(A, lds, threads, first_improvement, stream);
+#endif
 }
 
 // executed-evaluation counting (measurement hook) exists where gls_count_supported says; elsewhere a run that prunes cannot
