@@ -21,6 +21,8 @@ SIGNATURES = {
     "gnngls_last_error": [],
     "gnngls_gls_resident_capacity": [_int],
     "gnngls_gls_describe_config": [_int, _int, _int, _vp, _vp, _vp, _vp],
+    "gnngls_gls_describe_run": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "gnngls_gls_kernel_resources": [_int, _int, _int, _int, _int, _vp, _vp],
     "gnngls_two_opt_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_relocate_delta_all": [_vp, _vp, _int, _int, _vp, _vp],
     "gnngls_best_move": [_vp, _vp, _int, _int, _int, _vp, _int, _vp, _vp, _vp, _vp],

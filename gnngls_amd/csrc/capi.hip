@@ -93,7 +93,10 @@ GlsConfig gls_config(int n, int requested_bits, int batch = 0, bool first_improv
         // 10.3k (regret_pred of the synthetic model), 6.7k vs 6.8k (noise); but TSP100 x 256 on 8-wave workgroups 20.3k vs
         // 24.2k (model guide) and TSP50 x 128 (one pass per scan) 18.3k vs 21.2k: a round's barriers, slot exchange and
         // the re-evaluation after a move cost more than the few passes they save (profiles/r03_experiments/README.md)
-        const bool pays = batch > 0 && batch <= num_cus() && c.store == gnngls::GLS_STORE_COMPACT && c.threads == 1024;
+        // Round 5: the edge form of the serial phase (best improvement; gls_kernels.hip) beats the team form there too -- TSP200 x 256,
+        // outer iterations in 2 s, serial edge form vs team: 18.4k vs 15.1k (model guide), 18.8k vs 17.2k (weight) -- so the
+        // policy keeps the team form for first-improvement runs only (which have no edge form): profiles/r05_experiments/
+        const bool pays = first_improvement && batch > 0 && batch <= num_cus() && c.store == gnngls::GLS_STORE_COMPACT && c.threads == 1024;
         if (lds <= kLdsPerCU && (mode == 1 || pays)) { c.team = true; c.lds = lds; }
     }
     return c;
@@ -173,7 +176,7 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_impr
 
 extern "C" {
 
-int gnngls_abi_version(void) { return 2; }
+int gnngls_abi_version(void) { return 3; }
 const char *gnngls_last_error(void) { return g_err; }
 
 int gnngls_gls_resident_capacity(int n) {
@@ -194,6 +197,37 @@ int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *
     if (lds_bytes) *lds_bytes = (int)c.lds;
     if (per_cu) *per_cu = c.store == gnngls::GLS_STORE_GLOBAL ? 0 : c.per_cu;
     return GNNGLS_OK;
+}
+
+int gnngls_gls_describe_run(int n, int B, int penalty_bits, int first_improvement, int *store, int *threads, int *lds_bytes,
+                            int *per_cu, int *waves_per_simd, int *team, int *edge_form) {
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
+        return fail(GNNGLS_ERR_ARG, "gls_describe_run: bad argument");
+    const GlsConfig c = gls_config_run(n, penalty_bits, B, first_improvement != 0);      // exactly what gnngls_gls_run launches
+    if (c.lds > kLdsPerCU)
+        return fail(GNNGLS_ERR_UNSUPPORTED, "gls_describe_run: n=%d needs %zu B of LDS for tours and edge lengths (> 160 KiB)", n, c.lds);
+    if (store) *store = c.store * 100 + (c.store == gnngls::GLS_STORE_TRI ? c.penalty_bits : 0);
+    if (threads) *threads = c.threads;
+    if (lds_bytes) *lds_bytes = (int)c.lds;
+    if (per_cu) *per_cu = c.store == gnngls::GLS_STORE_GLOBAL ? 0 : c.per_cu;
+    if (waves_per_simd) *waves_per_simd = c.wps;
+    if (team) *team = c.team ? 1 : 0;
+    if (edge_form) *edge_form = gnngls::gls_edge_form(c.store, c.penalty_bits, c.wps, c.team, first_improvement != 0) ? 1 : 0;
+    return GNNGLS_OK;
+}
+
+int gnngls_gls_kernel_resources(int n, int B, int penalty_bits, int first_improvement, int trace, int *vgprs, int *scratch_bytes) {
+    if (n < 3 || B < 0 || (penalty_bits != 0 && penalty_bits != 16 && penalty_bits != 32 && penalty_bits != -1 && penalty_bits != -2))
+        return fail(GNNGLS_ERR_ARG, "gls_kernel_resources: bad argument");
+    const GlsConfig c = gls_config_run(n, penalty_bits, B, first_improvement != 0);
+    gnngls::GlsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = n; A.B = B;
+    static double dummy;
+    if (trace) { A.trace_cap = 1; A.trace_cost = &dummy; }                     // (selects the tracing instantiation; never dereferenced)
+    if (c.prune) { A.nl_id = reinterpret_cast<const uint8_t *>(&dummy); }     // (likewise)
+    const hipError_t e = gnngls::gls_kernel_resources(A, c.store, c.penalty_bits, c.threads, c.wps, c.team, first_improvement != 0, vgprs, scratch_bytes);
+    return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_kernel_resources");
 }
 
 int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits) {
@@ -302,19 +336,27 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (A.evals_exec) {          // the wavefronts of an instance add their counts atomically
         // a run that prunes on an instantiation without the counting code cannot report the executed evaluations: -1
         const bool unknown = cfg.prune && !gnngls::gls_count_supported(cfg.store, cfg.wps, n, first_improvement != 0, A.trace_cap > 0);
-        e = hipMemsetAsync(A.evals_exec, unknown ? 0xff : 0, (size_t)B * sizeof(long long), st);
+        e = hipMemsetAsync(A.evals_exec, 0, (size_t)5 * B * sizeof(long long), st);       // counts + the four cycle records
+        if (e == hipSuccess && unknown) e = hipMemsetAsync(A.evals_exec, 0xff, (size_t)B * sizeof(long long), st);
         if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: executed-evaluations buffer"); }
         if (unknown) A.evals_exec = nullptr;
+    }
+    int32_t *asym = nullptr;     // symmetric stores keep D[max, min] only: instances with an asymmetric matrix are flagged, not searched
+    if (cfg.store != gnngls::GLS_STORE_GLOBAL) {
+        e = hipMallocAsync((void **)&asym, (size_t)B * sizeof(int32_t), st);
+        if (e == hipSuccess) e = gnngls::launch_symmetry_check(D, B, n, asym, st);
+        if (e != hipSuccess) { if (asym) (void)hipFreeAsync(asym, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: symmetry check"); }
+        A.asym = asym;
     }
     void *nl = nullptr;          // nearest-neighbour lists of the pruned descent scans
     if (cfg.prune) {
         const size_t entries = (size_t)B * n * gnngls::kNeighborListLen;
         e = hipMallocAsync(&nl, (size_t)B * sizeof(int32_t) + entries, st);
-        if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour-list alloc"); }
+        if (e != hipSuccess) { if (asym) (void)hipFreeAsync(asym, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour-list alloc"); }
         int32_t *ok = (int32_t *)nl;
         uint8_t *nl_id = (uint8_t *)(ok + B);
         e = gnngls::launch_neighbor_lists(D, B, n, nl_id, ok, st);
-        if (e != hipSuccess) { (void)hipFreeAsync(nl, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour lists"); }
+        if (e != hipSuccess) { (void)hipFreeAsync(nl, st); if (asym) (void)hipFreeAsync(asym, st); if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: neighbour lists"); }
         A.nl_id = nl_id; A.prune_ok = ok;
     }
     {
@@ -322,6 +364,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
         e = gnngls::launch_gls(A, cfg.store, cfg.penalty_bits, cfg.threads, cfg.wps, cfg.team, first_improvement != 0, st);
     }
     if (nl) (void)hipFreeAsync(nl, st);
+    if (asym) (void)hipFreeAsync(asym, st);
     if (ws) (void)hipFreeAsync(ws, st);
     return e == hipSuccess ? GNNGLS_OK : hip_fail(e, "gls_run");
 }

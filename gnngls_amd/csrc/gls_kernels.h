@@ -5,6 +5,7 @@
 
 #define GNNGLS_STATUS_WATCHDOG_DEV 1
 #define GNNGLS_STATUS_PENALTY_OVERFLOW_DEV 2
+#define GNNGLS_STATUS_ASYMMETRIC_DEV 3
 
 namespace gnngls {
 
@@ -42,6 +43,7 @@ struct GlsArgs {
     // neighbor_lists_kernel; NULL = full scans
     const uint8_t *nl_id;      // [B,n,32] node ids, nearest first
     const int32_t *prune_ok;   // [B] 1 = the instance's matrix is within the magnitude bound of the pruning argument
+    const int32_t *asym;       // [B] 1 = the instance's matrix is not bitwise symmetric (symmetric stores: not searched, status 3); or NULL
 };
 
 enum { GLS_STORE_GLOBAL = 0, GLS_STORE_TRI = 1, GLS_STORE_COMPACT = 2 };
@@ -54,12 +56,16 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
 // team: perturbation phase on all wavefronts of the workgroup (for workgroups that own their CU); only where
 // gls_team_supported() says so
 bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads);
+bool gls_edge_form(int store, int penalty_bits, int wps, bool team, bool first_improvement);
 bool gls_wps2_supported(int store, int penalty_bits, int n, int threads, bool first_improvement);
 hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
                       hipStream_t stream);
+hipError_t gls_kernel_resources(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
+                                int *vgprs, int *scratch_bytes);
 constexpr int kNeighborListLen = 32;
 bool gls_prune_supported(int store, int n, bool first_improvement, int wps);
 bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool trace);
+hipError_t launch_symmetry_check(const double *D, int B, int n, int32_t *asym, hipStream_t stream);
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream);
 hipError_t launch_delta_all(const int32_t *tour, const double *D, int B, int n, int op, double *out, hipStream_t stream);
 hipError_t launch_best_move(const int32_t *tour, const double *D, int B, int n, int op, const int32_t *pos_i,

@@ -77,6 +77,9 @@ namespace gnngls {
 #ifndef GLS_SKIP_DEAD_PASS
 #define GLS_SKIP_DEAD_PASS 1         // pruned descent scans: a wavefront without rows in a pass skips it
 #endif
+#ifndef GLS_LEAN_SCALAR_TEST
+#define GLS_LEAN_SCALAR_TEST 0          // lean descent scans: scalar branch on a wave-wide test instead of an exec-masked one per step (A/B)
+#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
 #endif
@@ -857,11 +860,19 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             delta = delta + vd;                              // +D[d,b]
             delta = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
+#if GLS_LEAN_SCALAR_TEST
+            // one scalar branch on "some lane beats its best" (an exec-masked region costs ~45 cycles even when it skips nothing:
+            // profiles/r05_isa/); the per-lane test only behind it
+            if (__builtin_amdgcn_ballot_w64(delta < bd) != 0ull) {
+                if (delta < bd && (unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
+            }
+#else
             if (delta < bd) {
                 rare_path();
                 // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
                 if ((unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
             }
+#endif
         }
     };
     using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
@@ -928,10 +939,16 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
             delta = delta - eab;
             delta = delta - ecd[u];
+#if GLS_LEAN_SCALAR_TEST
+            if (__builtin_amdgcn_ballot_w64(delta < bd) != 0ull) {
+                if (delta < bd && j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
+            }
+#else
             if (delta < bd) {                                // j < i + 2 holds the mirrored move's delta: rarely below the best either
                 rare_path();
                 if (j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
             }
+#endif
         }
     };
     using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
@@ -1322,6 +1339,20 @@ __global__ void neighbor_lists_kernel(const double *D, int n, uint8_t *nl_id, in
     }
     bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) prune_ok[b] = !bad;
+}
+
+// asym[b] = 1 iff D_b is not bitwise symmetric (compared as bit patterns: NaNs and signed zeros included) -- one pass over
+// the matrices before a search on a symmetric store (1024 x TSP100: 82 MB, ~20 us)
+__global__ void symmetry_kernel(const double *D, int n, int32_t *asym) {
+    const int b = blockIdx.x;
+    const unsigned long long *Dg = reinterpret_cast<const unsigned long long *>(D) + (size_t)b * n * n;
+    int bad = 0;
+    for (int q = threadIdx.x; q < n * n; q += blockDim.x) {
+        const int a = q / n, c = q - a * n;
+        if (a < c && Dg[q] != Dg[(size_t)c * n + a]) bad = 1;
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) asym[b] = bad;
 }
 
 // o2a scans with an arbitrary distance functor (guided matrix in the perturbation phase).
@@ -1921,6 +1952,12 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 // dropped: evaluating several pending scans of a step at once, speculatively, in the reference's order of consumption (blocks
 // of two to four scans chosen by running acceptance estimates): bit-exact and 0.5-3 % slower than one scan at a time
 // (profiles/r05_experiments/).
+// -DGLS_ISA_MARKS (scripts/isa_critical_path.py): comment lines in the disassembly that delimit the regions of a penalty step
+#ifdef GLS_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; GLSMARK " name)
+#else
+#define ISA_MARK(name) do {} while (0)
+#endif
 #ifndef GLS_EDGE_PERTURB
 #define GLS_EDGE_PERTURB 1           // 0: the scan-by-scan serial form everywhere (A/B builds)
 #endif
@@ -1974,6 +2011,11 @@ __device__ __forceinline__ int pair_offset(int x, int xr, int y, int yr) {
     const lanemask_t gt = __builtin_amdgcn_ballot_w64(y > x);
     return sel_b32(gt, yr + 4 * x, xr + 4 * y);
 }
+// the same for two wave-uniform nodes: scalar max / min, no branch
+__device__ __forceinline__ int uniform_pair_offset(int x, int y) {
+    const int hi = x > y ? x : y, lo = x > y ? y : x;
+    return 2 * hi * (hi - 1) + 4 * lo;
+}
 // counter and distance of a node pair, in flight
 struct PairLoad { int p; double d; };
 template <class S>
@@ -2010,13 +2052,36 @@ __device__ __forceinline__ void edges_load(const S &s, TourEdges<GP> &E, const T
 }
 // the move (op, i, j) applied: new edges straight from the old tour (operators.py:6-11, 76-80), new tour written behind.
 // (lanes past the tour rewrite position 0 with the depot; position n always holds the depot in both tour arrays)
+// Both moves are "positions lo .. hi take the node of position sg p + add, one special position takes a given one":
+//   two_opt (i < j, operators.py:6-11):  lo = i, hi = j-1: i + j - 1 - p
+//   relocate i < j (operators.py:76-80): lo = i, hi = j:   p + 1, position j takes i;   i > j: lo = j, hi = i: p - 1, position j takes i
+// -- the parameters on the scalar unit once per move, the per-position part without a branch (move_src: three per call)
+struct MoveMap { int lo, span, sg, add, sp, sps; };
+__device__ __forceinline__ MoveMap move_map(int op, int i, int j) {
+    MoveMap m;
+    if (op == 0) {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        m.lo = a; m.span = b - 1 - a; m.sg = -1; m.add = a + b - 1; m.sp = -1; m.sps = 0;
+    } else if (i < j) {
+        m.lo = i; m.span = j - i; m.sg = 1; m.add = 1; m.sp = j; m.sps = i;
+    } else {
+        m.lo = j; m.span = i - j; m.sg = 1; m.add = -1; m.sp = j; m.sps = i;
+    }
+    return m;
+}
+__device__ __forceinline__ int move_src_flat(const MoveMap &m, int p) {
+    const lanemask_t in = __builtin_amdgcn_ballot_w64((unsigned)(p - m.lo) <= (unsigned)m.span);
+    const lanemask_t sp = __builtin_amdgcn_ballot_w64(p == m.sp);
+    return sel_b32(sp, m.sps, sel_b32(in, m.sg * p + m.add, p));
+}
 template <class S, int GP, class TT>
 __device__ __forceinline__ void edges_move(const S &s, TourEdges<GP> &E, const TT *told, TT *tnew, const double *guide,
                                            int n, int op, int i, int j, int lane) {
+    const MoveMap mm = move_map(op, i, j);
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
         const int p = lane + q * kWave, pc = p < n ? p : 0;
-        const int u = told[move_src(op, pc, i, j)], v = told[move_src(op, pc + 1, i, j)];
+        const int u = told[move_src_flat(mm, pc)], v = told[move_src_flat(mm, pc + 1)];
         E.u[q] = u; E.v[q] = v;
         tnew[pc] = (TT)u;
     }
@@ -2051,8 +2116,11 @@ __device__ __forceinline__ int argmax_first_pos(const double (&util)[GP], const 
     const lanemask_t tie = __builtin_amdgcn_ballot_w64(hi == mhi);
     if ((tie & (tie - 1)) == 0ull)                           // one lane holds the smallest high word: the usual case
         return __builtin_amdgcn_readlane(pos, __ffsll((long long)tie) - 1);
+    ISA_MARK("rare_argmax_tie");
     const unsigned mlo = wave_umin(hi == mhi ? lo : 0xffffffffu);
-    return (int)wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
+    const int r = (int)wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
+    ISA_MARK("argmax_reduce");
+    return r;
 }
 
 // One guided one-to-all scan at tour index i on the tour held by E: RELOC = false two_opt_o2a, true relocate_o2a.
@@ -2060,30 +2128,51 @@ __device__ __forceinline__ int argmax_first_pos(const double (&util)[GP], const 
 template <bool RELOC, class S, int GP>
 __device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, const TourEdges<GP> &E, const int lane, const int i,
                                                 const lanemask_t (&nm)[GP], double (&delta)[GP], lanemask_t (&ok)[GP]) {
+    ISA_MARK("scan_issue");
     const int na = edge_bcast<GP>(E.u, i), nb = edge_bcast<GP>(E.u, i - 1);       // a = t[i], b = t[i-1]
     const int nar = 2 * na * (na - 1), nbr = 2 * nb * (nb - 1);
     PairLoad x0[GP], x1[GP], xac;
     if (RELOC) {                                             // G[t[i-1], t[i+1]]: a wave-uniform pair
         const int nc = edge_bcast<GP>(E.v, i);
-        xac = pair_issue(s, nc > nb ? 2 * nc * (nc - 1) + 4 * nb : nbr + 4 * nc);
+        xac = pair_issue(s, uniform_pair_offset(nb, nc));
     }
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
-        x0[q] = pair_issue(s, pair_offset(na, nar, E.v[q], E.vr[q]));                             // G[t[i], t[k+1]]
-        x1[q] = RELOC ? pair_issue(s, pair_offset(na, nar, E.u[q], E.ur[q]))                      // G[t[i], t[k]]
-                      : pair_issue(s, pair_offset(nb, nbr, E.u[q], E.ur[q]));                     // G[t[i-1], t[k]]
+        x0[q] = pair_issue(s, pair_offset(na, nar, E.v[q], E.vr[q]));                           // G[t[i], t[k+1]]
+        x1[q] = RELOC ? pair_issue(s, pair_offset(na, nar, E.u[q], E.ur[q]))                    // G[t[i], t[k]]
+                      : pair_issue(s, pair_offset(nb, nbr, E.u[q], E.ur[q]));                   // G[t[i-1], t[k]]
     }
-    // every load of the scan in flight before the first is consumed (cf. scan_two_opt_o2a_guided_rm)
-#pragma unroll
-    for (int q = 0; q < GP; ++q) { pin(x0[q]); pin(x1[q]); }
-    if (RELOC) pin(xac);
+    ISA_MARK("scan_under_latency");
+    // under the loads' latency: everything that does not need them -- the guided lengths of the tour edges (registers), the
+    // scan's own edges (v_readlane), the subtrahends and validity masks of the lanes
     double ge[GP];                                           // guided length of the lane's own edges
 #pragma unroll
     for (int q = 0; q < GP; ++q) ge[q] = E.de[q] + k * (double)E.pq[q];
     const double gab = edge_bcast_f64<GP>(ge, i - 1);        // G[t[i-1], t[i]]
+    double gbc = 0.0;
+    if (RELOC) gbc = edge_bcast_f64<GP>(ge, i);              // G[t[i], t[i+1]]
+    double s1[GP], s2[GP];                                   // two_opt_o2a: first and second subtrahend of the lane
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        const int kk = lane + q * kWave;
+        if (!RELOC) {
+            // j = k + 1 > i: - G[a,b] of the scan's edge, then - G[c,d] of the lane's; j < i (operators.py:17-18 swap): the other way
+            const lanemask_t lt = __builtin_amdgcn_ballot_w64(kk >= i);
+            s1[q] = sel_f64(lt, gab, ge[q]); s2[q] = sel_f64(lt, ge[q], gab);
+            // j = 1 .. n-1, |i - j| >= 2 (operators.py:59-62): k <= n-2, k not in {i-2, i-1, i}
+            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 2) > 2u);
+        } else {
+            // j != i (operators.py:114-115): k <= n-1, k not in {i-1, i}
+            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 1) > 1u);
+        }
+    }
+    // every load of the scan was issued before the first is consumed (cf. scan_two_opt_o2a_guided_rm)
+    ISA_MARK("scan_wait_and_arith");
+#pragma unroll
+    for (int q = 0; q < GP; ++q) { pin(x0[q]); pin(x1[q]); asm volatile("" : "+v"(ge[q])); if (!RELOC) asm volatile("" : "+v"(s1[q]), "+v"(s2[q])); }
     double base = 0.0;
     if (RELOC) {
-        const double gbc = edge_bcast_f64<GP>(ge, i);        // G[t[i], t[i+1]]
+        pin(xac);
         base = -gab;                                         // operators.py:97-99, left to right
         base = base - gbc;
         base = base + guided(k, xac);
@@ -2091,25 +2180,19 @@ __device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, cons
     lanemask_t neg = 0ull;
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
-        const int kk = lane + q * kWave;
         const double gav = guided(k, x0[q]), gxu = guided(k, x1[q]);
         double d;
         if (!RELOC) {
-            // two_opt_o2a (operators.py:53-73), j = k + 1: c = t[j] = v, d = t[j-1] = u; j > i: ((G[a,c] + G[b,d]) - G[a,b]) - G[c,d];
-            // j < i (operators.py:17-18 swap): the same sum, then G[c,d] of the lane's edge first, the scan's edge last
-            const lanemask_t lt = __builtin_amdgcn_ballot_w64(kk >= i);
+            // two_opt_o2a (operators.py:53-73), j = k + 1: c = t[j] = v, d = t[j-1] = u: ((G[a,c] + G[b,d]) - G[a,b]) - G[c,d]
             d = gav + gxu;
-            d = d - sel_f64(lt, gab, ge[q]);
-            d = d - sel_f64(lt, ge[q], gab);
-            // j = 1 .. n-1, |i - j| >= 2 (operators.py:59-62): k <= n-2, k not in {i-2, i-1, i}
-            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 2) > 2u);
+            d = d - s1[q];
+            d = d - s2[q];
         } else {
             // relocate_o2a (operators.py:106-126) by target edge k = (d, e) = (u, v): ((base - G[d,e]) + G[d,b]) + G[b,e], b = t[i];
             // j = k for i < j, j = k + 1 for i > j (operators.py:91-96); j != i: k not in {i-1, i}
             d = base - ge[q];
             d = d + gxu;
             d = d + gav;
-            ok[q] = nm[q] & __builtin_amdgcn_ballot_w64((unsigned)(kk - i + 1) > 1u);
         }
         delta[q] = d;
         neg |= ok[q] & __builtin_amdgcn_ballot_w64(d < 0.0);
@@ -2117,11 +2200,11 @@ __device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, cons
     return neg;
 }
 
-template <class S, int GP, bool TR, class TT, class TRC>
+template <class S, int GP, bool TR, bool CNT, class TT, class TRC>
 __device__ __forceinline__ void serial_perturbation_edges(const S &s, const double k, TT *&t, TT *&t2, double *Ef, double *Eb,
                                                           const int n, const double *guide, const GlsArgs &A,
                                                           const long long t_start, double &cur_cost, TRC &tr,
-                                                          long long &evals, int &status, Stamps &st) {
+                                                          long long &evals, int &status, long long &steps_total, Stamps &st) {
     static_assert(S::kSymmetric && sizeof(typename S::pen_t) == 4, "edge form: symmetric stores with 32-bit counters");
     constexpr bool eager_cost = TR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -2137,14 +2220,24 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
     bool any_moved = false;
     int moves = 0, scans_to = 0, scans_re = 0;               // one-to-all scans executed (evaluation count, booked at the end)
     long long steps = 0;
-    const int max_moves = A.perturbation_moves;
+    int max_moves = A.perturbation_moves;
+    asm volatile("" : "+s"(max_moves));                      // a register, not a kernel-argument load (and its wait) per step
     while (moves < max_moves) {
         // ---- arg-max utility over the tour edges, first maximum wins (algorithms.py:153-159); only its position is used ----
+        STAMP_END(12);      // (diagnostic builds: end of the previous step / loop latch)
+        ISA_MARK("argmax_divisions");
         double util[GP];
 #pragma unroll
         for (int q = 0; q < GP; ++q) util[q] = E.gq[q] / (1.0 + (double)E.pq[q]);     // lanes past the tour hold edge 0: masked
+#ifdef GLS_STAMPS
+#pragma unroll
+        for (int q = 0; q < GP; ++q) asm volatile("" : "+v"(util[q]));
+        STAMP_END(13);      // (the divisions, behind the loads of the last move)
+#endif
+        ISA_MARK("argmax_reduce");
         const int bp = argmax_first_pos<GP>(util, nm0, lane);
         STAMP_END(0);
+        ISA_MARK("penalise");
         const int eu = edge_bcast<GP>(E.u, bp), ev = edge_bcast<GP>(E.v, bp);
         // algorithms.py:161: the lane that holds edge bp stores count + 1 itself (no load -> add -> store round trip)
         {
@@ -2157,12 +2250,13 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
                 cnt = sel_b32(o, E.pq[q], cnt);
                 own |= o;
             }
-            s.pen_store_byte_if(own, eu > ev ? 2 * eu * (eu - 1) + 4 * ev : 2 * ev * (ev - 1) + 4 * eu, cnt);
+            s.pen_store_byte_if(own, uniform_pair_offset(eu, ev), cnt);
         }
         int i = bp;                                          // algorithms.py:169: the edge was read at positions bp, bp + 1
         bool moved_this_step = false;
 #pragma unroll 1
         for (int sc = eu == 0 ? 2 : 0; sc < (ev == 0 ? 2 : 4); ++sc) {      // scan = 2 endpoint + operator; algorithms.py:167-171
+            ISA_MARK("scan_loop_head");
             if (sc == 2) {                                   // endpoint 1: cur_tour.index(ev), searched only after a move
                 i = bp + 1;
                 if (moved_this_step) {
@@ -2178,9 +2272,11 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
             const bool reloc = (sc & 1) != 0;
             const lanemask_t neg = reloc ? eval_scan<true, S, GP>(s, k, E, lane, i, nm0, delta, ok)
                                          : eval_scan<false, S, GP>(s, k, E, lane, i, nm2, delta, ok);
+            ISA_MARK("accept_fast");
             if (reloc) scans_re += 1; else scans_to += 1;
             STAMP_END(1);
             if (neg == 0ull) continue;                       // no negative delta: no candidate (most scans)
+            ISA_MARK("accept_slow");
             // np.isclose evaluated literally; the keys of a lane ascend with its slots, so a strict < keeps the lane's first
             // minimum (operators.py:65,118)
             double bd = 0.0; int bk = kNoKey;
@@ -2197,6 +2293,7 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
             wave_reduce_best<false>(bd, bk);
             bk = __builtin_amdgcn_readfirstlane(bk);
             STAMP_END(2);
+            ISA_MARK("move");
             edges_move(s, E, t, t2, guide, n, sc & 1, i, bk, lane);          // algorithms.py:175-177
             { TT *x = t; t = t2; t2 = x; }
             any_moved = true; moved_this_step = true;
@@ -2209,18 +2306,24 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
                 if (lane == 0) tr.push(cur_cost);
             }
             STAMP_END(3);
+            ISA_MARK("scan_loop_tail");
         }
+        ISA_MARK("step_tail");
         steps++;
         STAMP_COUNT(6);
         if ((steps & 63) == 0) {
+            ISA_MARK("rare_watchdog");
             const long long el = wall_clock64() - t_start;
             if (el > (long long)(A.watchdog_s * 1e8)) { status = GNNGLS_STATUS_WATCHDOG_DEV; break; }
         }
+        ISA_MARK("step_tail");
     }
+    ISA_MARK("phase_end");
     if (lane == 0) {
         evals += (long long)scans_to * (n - 3) + (long long)scans_re * (n - 2);
         if (!eager_cost) tr.len += moves;                    // moves counted, costs deferred
     }
+    if constexpr (CNT) steps_total += steps;                 // (measurement builds: penalty steps of the run, GlsArgs::evals_exec)
     if (any_moved && !eager_cost) {
         wave_sync();
         build_edges(s, t, Ef, Eb, n, lane, kWave);
@@ -2253,6 +2356,24 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
     const size_t nn = (size_t)n * n;
     const double *Dg = A.D + (size_t)b * nn;
 
+    if constexpr (S::kSymmetric) {
+        // the symmetric stores keep D[max, min] only: an instance whose matrix is not bitwise symmetric (symmetry_kernel) is NOT
+        // searched -- it would be a different search than the reference's (operators.py reads D[a,b] as indexed) -- but handed
+        // back untouched with GNNGLS_STATUS_ASYMMETRIC; the caller reruns it on the global-memory store (gnngls_amd.ops does)
+        if (A.asym && A.asym[b]) {
+            for (int p = tid; p <= n; p += nthr) A.best_tour[(size_t)b * (n + 1) + p] = A.init_tour[(size_t)b * (n + 1) + p];
+            if (tid == 0) {
+                A.best_cost[b] = A.init_cost[b];
+                if (A.outer_iters) A.outer_iters[b] = 0;
+                if (A.trace_len) A.trace_len[b] = 0;
+                if (A.evals) A.evals[b] = 0;
+                if (A.imp_len) A.imp_len[b] = 0;
+                if (A.status) A.status[b] = GNNGLS_STATUS_ASYMMETRIC_DEV;
+            }
+            if (A.penalty_out) for (size_t q = tid; q < nn; q += nthr) A.penalty_out[(size_t)b * nn + q] = 0;
+            return;
+        }
+    }
     // ---- LDS carve (all offsets multiples of 16) ----
     size_t off = 0;
     Ctl *ctl = reinterpret_cast<Ctl *>(smem + off);            off += (sizeof(Ctl) + 15) & ~size_t(15);
@@ -2358,6 +2479,8 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
     __syncthreads();
 
     long long iter_i = 0;
+    long long pert_cycles = 0, pert_steps = 0;      // counting instantiations: shader cycles and penalty steps of the serial perturbation phase
+    const long long c_start = CNT ? clock64() : 0;
     for (;;) {
         // ---- loop condition (algorithms.py:146) ----
         if (tid == 0) {
@@ -2384,7 +2507,10 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
             // waves of the other resident workgroups on the same SIMD: give it priority while it runs
             __builtin_amdgcn_s_setprio(GLS_PERTURB_PRIO);
             if constexpr (kEdgeForm) {
-                serial_perturbation_edges<S, GP, TR>(s, k, t, t2, Ef, Eb, n, guide, A, t_start, cur_cost, tr, evals, status, st);
+                long long pc0 = 0;
+                if constexpr (CNT) pc0 = clock64();
+                serial_perturbation_edges<S, GP, TR, CNT>(s, k, t, t2, Ef, Eb, n, guide, A, t_start, cur_cost, tr, evals, status, pert_steps, st);
+                if constexpr (CNT) pert_cycles += clock64() - pc0;
             } else {
             bool any_moved = false;
             int moves = 0;
@@ -2539,6 +2665,14 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         // the pruned scans minus those scans' reference counts).  Zeroed by the host.
         if (A.evals_exec && lane == 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(A.evals_exec + b), (unsigned long long)(xe + (tid == 0 ? evals : 0ll)));
+        // ... and the cycle budget of the run for bench.py's critical-path figure: [B .. 5B) of the same buffer = shader cycles
+        // of the kernel, shader cycles and penalty steps of the serial perturbation phase (edge form; else 0), 100 MHz ticks
+        if (A.evals_exec && tid == 0) {
+            A.evals_exec[(size_t)A.B + b] = clock64() - c_start;
+            A.evals_exec[(size_t)2 * A.B + b] = pert_cycles;
+            A.evals_exec[(size_t)3 * A.B + b] = pert_steps;
+            A.evals_exec[(size_t)4 * A.B + b] = wall_clock64() - t_start;
+        }
     } else if (A.evals_exec && tid == 0) {
         // the host only hands this instantiation the buffer when no scan of the run is pruned: executed = reference count
         A.evals_exec[b] = evals;
@@ -2559,7 +2693,8 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         // descent's scan cycles and its arg-min + wait cycles
         long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
         if (TEAM) o2[wave] = st.acc[12];
-        else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; o2[4] = st.acc[15]; }   // pruned-scan counters
+        else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; o2[4] = st.acc[15];      // pruned-scan counters
+                              o2[5] = st.acc[12]; o2[6] = st.acc[13]; o2[7] = st.acc[14]; }   // edge form: latch, divisions
         o2[(size_t)A.B * 16 + wave] = st.acc[8];
         o2[(size_t)A.B * 32 + wave] = st.acc[9];
     }
@@ -2741,9 +2876,14 @@ int gls_waves_per_simd(int store, int n, int batch, int num_cus, int threads, si
     return (batch > 0 && (long)per_cu4 * num_cus < batch && 32 / waves > per_cu4 && by_lds > per_cu4) ? 8 : 4;
 }
 
+// resource query (gls_kernel_resources): with the slot set, the launch chain stops at the selected instantiation and hands back
+// its function instead of launching it
+static thread_local const void **t_query_fn = nullptr;
+
 template <class S, bool FI, int GP, bool TR, int WPS, bool TEAM, bool CNT = false>
 static hipError_t launch_gls_k(const GlsArgs &A, size_t lds, int threads, hipStream_t stream) {
     auto kern = gls_kernel<S, FI, GP, TR, WPS, TEAM, CNT>;
+    if (t_query_fn) { *t_query_fn = reinterpret_cast<const void *>(kern); return hipSuccess; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -2759,6 +2899,10 @@ static hipError_t launch_gls_g(const GlsArgs &A, size_t lds, int threads, hipStr
     if constexpr (!FI && WPS == 4 && GP >= 2 && std::is_base_of<TriDGlobalP, S>::value) {
         if (A.evals_exec && A.nl_id && !(A.trace_cap > 0 && A.trace_cost)) return launch_gls_k<S, FI, GP, false, WPS, TEAM, true>(A, lds, threads, stream);
     }
+    // (a run that prunes AND asks for the executed-evaluation count must have landed on a counting instantiation above: the
+    // others would report executed == reference evaluations, a silently wrong ratio -- gls_count_supported() is the host's copy
+    // of the rule)
+    if (A.evals_exec && A.nl_id) return hipErrorInvalidValue;
     // trace_cap == 0 (no trace buffer): the trace-free instantiation (fewer live registers in the serial phase)
     if (A.trace_cap > 0 && A.trace_cost) return launch_gls_k<S, FI, GP, true, WPS, TEAM>(A, lds, threads, stream);
     return launch_gls_k<S, FI, GP, false, WPS, TEAM>(A, lds, threads, stream);
@@ -2793,6 +2937,12 @@ bool gls_wps2_supported(int store, int penalty_bits, int n, int threads, bool fi
            penalty_bits == 32 && (store == GLS_STORE_COMPACT || store == GLS_STORE_TRI);
 }
 
+// the serial perturbation phase runs in its edge form (serial_perturbation_edges) on the symmetric stores with 32-bit counters,
+// best improvement, the 128-VGPR and wider builds -- the host's copy of kEdgeForm in gls_kernel
+bool gls_edge_form(int store, int penalty_bits, int wps, bool team, bool first_improvement) {
+    return GLS_EDGE_PERTURB && store != GLS_STORE_GLOBAL && !(store == GLS_STORE_TRI && penalty_bits == 16) && !first_improvement && !team && wps <= 4;
+}
+
 bool gls_team_supported(int store, int penalty_bits, int wps, int n, int threads) {
     // the team form exists for the 128-VGPR builds of the two symmetric stores with 32-bit counters, n <= 255; it caches the
     // utilities of the tour edges by position on wavefronts 0 .. ceil(n / 64) - 1, so the workgroup needs that many
@@ -2807,7 +2957,7 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
 #ifdef GLS_DEV_ONLY_HEADLINE
     // development builds (ISA inspection, fast compiles): only the instantiation the TSP100 x 1024 headline runs on
     (void)store; (void)penalty_bits; (void)wps; (void)first_improvement;
-    return launch_gls_k<TriDGlobalP, false, 2, false, 4, false>(A, lds, threads, stream);
+    return launch_gls_k<TriDGlobalP, false, GLS_DEV_ONLY_HEADLINE + 0 == 4 ? 4 : 2, false, 4, false>(A, lds, threads, stream);   // (-DGLS_DEV_ONLY_HEADLINE=4: TSP200's)
 #else
 #if GLS_WPS2
     if (wps == 2) {          // single-wavefront workgroups on the 256-VGPR build (gls_wps2_supported)
@@ -2832,6 +2982,23 @@ hipError_t launch_gls(const GlsArgs &A, int store, int penalty_bits, int threads
 #endif
 }
 
+// registers and scratch of the instantiation launch_gls would run for these arguments (hipFuncGetAttributes: needs the device)
+hipError_t gls_kernel_resources(const GlsArgs &A, int store, int penalty_bits, int threads, int wps, bool team, bool first_improvement,
+                                int *vgprs, int *scratch_bytes) {
+    const void *fn = nullptr;
+    t_query_fn = &fn;
+    const hipError_t e = launch_gls(A, store, penalty_bits, threads, wps, team, first_improvement, nullptr);
+    t_query_fn = nullptr;
+    if (e != hipSuccess) return e;
+    if (!fn) return hipErrorInvalidValue;
+    hipFuncAttributes at;
+    const hipError_t e2 = hipFuncGetAttributes(&at, fn);
+    if (e2 != hipSuccess) return e2;
+    if (vgprs) *vgprs = at.numRegs;
+    if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
+    return hipSuccess;
+}
+
 // executed-evaluation counting (measurement hook) exists where gls_count_supported says; elsewhere a run that prunes cannot
 // report it
 bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool trace) {
@@ -2843,6 +3010,12 @@ bool gls_count_supported(int store, int wps, int n, bool first_improvement, bool
 // lists must be full (n - 1 >= 32)
 bool gls_prune_supported(int store, int n, bool first_improvement, int wps) {
     return store != GLS_STORE_GLOBAL && !first_improvement && n >= kPruneMinNodes && n <= 255 && wps <= GLS_PRUNE_MAX_WPS;
+}
+
+hipError_t launch_symmetry_check(const double *D, int B, int n, int32_t *asym, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(symmetry_kernel, dim3(B), dim3(256), 0, stream, D, n, asym);
+    return hipGetLastError();
 }
 
 hipError_t launch_neighbor_lists(const double *D, int B, int n, uint8_t *nl_id, int32_t *prune_ok, hipStream_t stream) {

@@ -112,12 +112,12 @@ class GlsResult:
         return self.trace_len > cap
 
 
-STATUS_OK, STATUS_WATCHDOG, STATUS_PENALTY_OVERFLOW = 0, 1, 2
+STATUS_OK, STATUS_WATCHDOG, STATUS_PENALTY_OVERFLOW, STATUS_ASYMMETRIC = 0, 1, 2, 3
 
 
 def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improvement=False,
             max_outer_iters=-1, time_limit_s=0.0, watchdog_s=None, trace_cap=0, want_trace_time=False,
-            want_penalty=False, penalty_bits=0, retry_overflow=True, imp_cap=0):
+            want_penalty=False, penalty_bits=0, retry_overflow=True, imp_cap=0, retry_asymmetric=True):
     """guided_local_search (reference algorithms.py:135-195) for a batch of instances.
 
     D [B,n,n] fp64 symmetric, guides [G,B,n,n] fp64 (or None when max_outer_iters == 0 ->
@@ -125,6 +125,8 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
     penalty_bits: 0 = auto (see include/gnngls_hip.h).  With retry_overflow (default) instances whose
     16-bit penalty counters overflowed are rerun with 32-bit counters (needs a host sync).
     (Such a rerun gets the same time_limit_s again: with penalty_bits=16 a wall-clock run can take twice the limit.)
+    With retry_asymmetric (default) instances whose matrix is not bitwise symmetric (status STATUS_ASYMMETRIC: flagged on the
+    device, not searched) are rerun on the global-memory store (penalty_bits = -1), which accepts any matrix (needs a host sync).
     imp_cap > 0 records the improvement trace (bounded however long the run is; see include/gnngls_hip.h).
     watchdog_s: None = time_limit_s + 5 s in wall-clock mode; in iteration-count mode a bound that scales with the
     requested work (the caller asked for exactly that many iterations, so the watchdog only catches hangs)."""
@@ -163,6 +165,20 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
         _lib.current_stream()), "gls_run")
     res = GlsResult(best_tour, best_cost, outer, trace_cost, trace_time, trace_len, penalty, evals, status,
                     imp_cost, imp_time, imp_iter, imp_len)
+    if retry_asymmetric and penalty_bits != -1:
+        # instances whose matrix is not bitwise symmetric were flagged, not searched (the symmetric stores keep one triangle):
+        # rerun them on the global-memory store, which follows the reference's index order (operators.py:25-28,97-102)
+        bad = (status == STATUS_ASYMMETRIC).nonzero().flatten()
+        if bad.numel() > 0:
+            sub = gls_run(D[bad].contiguous(), None if guides is None else guides[:, bad].contiguous(),
+                          init_tour[bad].contiguous(), init_cost[bad].contiguous(), perturbation_moves,
+                          first_improvement, max_outer_iters, time_limit_s, watchdog_s, trace_cap, want_trace_time,
+                          want_penalty, penalty_bits=-1, retry_overflow=False, imp_cap=imp_cap, retry_asymmetric=False)
+            for name in ("best_tour", "best_cost", "outer_iters", "trace_cost", "trace_time", "trace_len", "penalty",
+                         "evals", "status", "imp_cost", "imp_time", "imp_iter", "imp_len"):
+                dst, src = getattr(res, name), getattr(sub, name)
+                if dst is not None:
+                    dst[bad] = src
     if retry_overflow and penalty_bits in (0, 16):
         bad = (status == STATUS_PENALTY_OVERFLOW).nonzero().flatten()
         if bad.numel() > 0:
@@ -176,6 +192,15 @@ def gls_run(D, guides, init_tour, init_cost, perturbation_moves=30, first_improv
                 if dst is not None:
                     dst[bad] = src
     return res
+
+
+def gls_kernel_resources(n, B=0, penalty_bits=0, first_improvement=False, trace=False):
+    """-> dict(vgprs, scratch_bytes) of the kernel instantiation gls_run would launch (needs the device)."""
+    v, sc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.load().gnngls_gls_kernel_resources(int(n), int(B), int(penalty_bits), int(bool(first_improvement)), int(bool(trace)),
+                                                       ctypes.cast(ctypes.byref(v), ctypes.c_void_p), ctypes.cast(ctypes.byref(sc), ctypes.c_void_p)),
+               "gls_kernel_resources")
+    return {"vgprs": v.value, "scratch_bytes": sc.value}
 
 
 def gls_resident_capacity(n):
@@ -223,10 +248,20 @@ class executed_evals:
     the block runs the COUNTING instantiation of the kernel (2-3 % slower): measure speed outside of it."""
 
     def __init__(self, capacity):
-        self.counts = torch.zeros((int(capacity),), dtype=torch.int64, device=_dev())
+        self.capacity = int(capacity)
+        self.buffer = torch.zeros((5 * self.capacity,), dtype=torch.int64, device=_dev())
+
+    def record(self, B, k):
+        """Record k of the LAST launch of B instances inside the block: 0 executed evaluations, 1 shader cycles of the
+        workgroup, 2 shader cycles of its serial perturbation phase, 3 penalty steps of that phase, 4 100 MHz ticks."""
+        return self.buffer[k * B:(k + 1) * B]
+
+    @property
+    def counts(self):
+        return self.buffer[:self.capacity]
 
     def __enter__(self):
-        _lib.check(_lib.load().gnngls_profile_set_executed_evals(_lib.ptr(self.counts)), "profile_set_executed_evals")
+        _lib.check(_lib.load().gnngls_profile_set_executed_evals(_lib.ptr(self.buffer)), "profile_set_executed_evals")
         return self
 
     def __exit__(self, *exc):
@@ -234,13 +269,20 @@ class executed_evals:
         return False
 
 
-def gls_describe_config(n, B=0, penalty_bits=0):
-    """-> dict(store, threads, lds_bytes, per_cu, team, waves_per_simd): what gnngls_gls_run would use (host-side query)."""
-    vals = [ctypes.c_int(0) for _ in range(4)]
-    _lib.check(_lib.load().gnngls_gls_describe_config(int(n), int(B), int(penalty_bits),
-                                                      *[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals]),
-               "gls_describe_config")
+def gls_describe_config(n, B=0, penalty_bits=0, first_improvement=False):
+    """-> dict(store, threads, lds_bytes, per_cu, team, waves_per_simd[, edge_form]): exactly what gnngls_gls_run launches for
+    these arguments (host-side query, gnngls_gls_describe_run).  `edge_form` (the serial perturbation phase with the tour edges
+    in registers) is reported under its own key by gls_describe_run()."""
+    d = gls_describe_run(n, B, penalty_bits, first_improvement)
+    d.pop("edge_form")
+    return d
+
+
+def gls_describe_run(n, B=0, penalty_bits=0, first_improvement=False):
+    vals = [ctypes.c_int(0) for _ in range(7)]
+    _lib.check(_lib.load().gnngls_gls_describe_run(int(n), int(B), int(penalty_bits), int(bool(first_improvement)),
+                                                   *[ctypes.cast(ctypes.byref(v), ctypes.c_void_p) for v in vals]),
+               "gls_describe_run")
     names = {0: "global", 116: "lds-tri-u16", 132: "lds-tri-i32", 200: "compact"}
     return {"store": names[vals[0].value], "threads": vals[1].value, "lds_bytes": vals[2].value, "per_cu": vals[3].value,
-            "team": bool(_lib.load().gnngls_gls_uses_team(int(n), int(B), int(penalty_bits))),
-            "waves_per_simd": _lib.load().gnngls_gls_waves_per_simd(int(n), int(B), int(penalty_bits))}
+            "team": bool(vals[5].value), "waves_per_simd": vals[4].value, "edge_form": bool(vals[6].value)}

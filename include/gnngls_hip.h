@@ -40,6 +40,10 @@ extern "C" {
 #define GNNGLS_STATUS_OK 0
 #define GNNGLS_STATUS_WATCHDOG 1      /* watchdog fired (search aborted, best-so-far returned) */
 #define GNNGLS_STATUS_PENALTY_OVERFLOW 2   /* a 16-bit LDS penalty counter would pass 65535: rerun with penalty_bits=32 */
+#define GNNGLS_STATUS_ASYMMETRIC 3    /* the instance's matrix is not bitwise symmetric and the run was on a store that keeps one
+                                         triangle (every store but the global-memory one): NOT searched -- best = the start tour,
+                                         0 iterations -- because the reference reads D[a,b] as indexed (operators.py:25-28,97-102)
+                                         and the search would differ; rerun the instance with penalty_bits = -1 */
 
 int gnngls_abi_version(void);
 const char *gnngls_last_error(void);
@@ -54,6 +58,21 @@ int gnngls_gls_resident_capacity(int n);
  *              200 = compact store (distance triangle in LDS, penalties in global memory)
  *   *threads   workgroup size, *lds_bytes dynamic LDS per workgroup, *per_cu resident workgroups per CU (0: n/a) */
 int gnngls_gls_describe_config(int n, int B, int penalty_bits, int *store, int *threads, int *lds_bytes, int *per_cu);
+
+/* The same query for exactly the launch gnngls_gls_run(…, first_improvement, penalty_bits, …) makes (ABI v3).  The three
+ * older queries -- gnngls_gls_describe_config, gnngls_gls_waves_per_simd, gnngls_gls_uses_team -- answer for a
+ * best-improvement run; a first-improvement run can use another workgroup size (n = 25..33), register budget and form of
+ * the perturbation phase.  *waves_per_simd, *team as documented there; *edge_form = 1 if the serial perturbation phase
+ * (algorithms.py:150-185) runs in its edge form (tour edges in registers; symmetric stores, 32-bit counters, best
+ * improvement), 0 for the scan-by-scan form.  Any output pointer may be NULL. */
+int gnngls_gls_describe_run(int n, int B, int penalty_bits, int first_improvement, int *store, int *threads, int *lds_bytes,
+                            int *per_cu, int *waves_per_simd, int *team, int *edge_form);
+
+/* Vector registers per lane and scratch bytes per lane of the kernel instantiation that launch would run (trace != 0: with a
+ * per-move trace buffer) -- hipFuncGetAttributes on the selected function, so it needs the device.  Every BASELINE.json shape
+ * runs on an instantiation without scratch; tests/test_perf_floor_gpu.py asserts it so that a code-generation regression in
+ * this ~70-instantiation kernel shows in the driver's GPU tests. */
+int gnngls_gls_kernel_resources(int n, int B, int penalty_bits, int first_improvement, int trace, int *vgprs, int *scratch_bytes);
 
 /* ---- K3u: move-evaluation tables (parity/unit kernels) ---------------------------------------
  * out[b][i][j] (shape [B, n+1, n+1]) = two_opt_cost(tour_b, D_b, i, j)   operators.py:14-29
@@ -203,9 +222,11 @@ int gnngls_gls_waves_per_simd(int n, int B, int penalty_bits);
 
 /* 1 if gnngls_gls_run would run the perturbation phase of this (n, B, penalty_bits) on ALL wavefronts of the workgroup
  * (the "team" form: the four one-to-all scans of a penalty step, algorithms.py:167-174, evaluated concurrently and consumed
- * in the reference's order), 0 if on wavefront 0 only.  The policy picks it for 16-wave workgroups that own a CU by their
- * LDS footprint (compact store, n >= 144: TSP200) when B <= number of CUs -- where it was measured faster.  Same results
- * either way (bit-exact); this only reports the policy. */
+ * in the reference's order), 0 if on wavefront 0 only.  Since round 5 the policy picks it for FIRST-IMPROVEMENT runs only
+ * (16-wave workgroups that own a CU by their LDS footprint -- compact store, n >= 144: TSP200 -- when B <= number of CUs):
+ * for best-improvement runs the edge form of the serial phase is faster there too, so this query (a best-improvement
+ * answer) returns 0 unless the test hook below forces the form; gnngls_gls_describe_run reports a first-improvement launch.
+ * Same results either way (bit-exact); this only reports the policy. */
 int gnngls_gls_uses_team(int n, int B, int penalty_bits);
 
 /* Experiment / test hook: -1 = the policy above (default), 0 = never use the team form, 1 = use it wherever it exists
@@ -244,8 +265,12 @@ int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);
  * the perturbation phase every move once -- so executed <= evals_out, equal where nothing is pruned.  Counting costs the
  * pruned scans 2-3 % (profiles/r04_ab_exec_counter.log), so it lives in kernel instantiations of their own that ONLY a
  * launch with this hook set selects: compact store (penalty_bits 0 / -2 where that store is picked), best improvement, no
- * per-move trace.  A pruning run on any other configuration reports -1 per instance.  The buffer must hold the largest B
- * launched while it is set; process-wide, not per stream. */
+ * per-move trace.  A pruning run on any other configuration reports -1 per instance.
+ * ABI v3: the buffer holds 5 x B int64 -- [0, B) the counts above, then four records of the same launch for bench.py's
+ * critical-path figure (written by the counting instantiations, else 0): [B, 2B) shader cycles of the instance's workgroup,
+ * [2B, 3B) shader cycles of its serial perturbation phase (algorithms.py:150-185, wavefront 0), [3B, 4B) penalty steps of
+ * that phase (edge form), [4B, 5B) 100 MHz device-clock ticks of the workgroup.  It must hold 5 x the largest B launched
+ * while it is set; process-wide, not per stream. */
 int gnngls_profile_set_executed_evals(int64_t *device_buffer);
 
 #ifdef __cplusplus

@@ -49,7 +49,10 @@ it = r.outer_iters.double().mean().item()
 print(f"outer iters {it:.0f}, perturbation steps/iter {st[6] / it:.1f}")
 for k in range(6):
     print(f"{names[k]:30s} {st[k] / tot * 100:5.1f}%   {st[k] / it:9.0f} cycles/outer-iter")
-print(f"cycles per perturbation step (wave 0): {(st[0] + st[1] + st[2] + st[3]) / st[6]:.0f}")
+print(f"cycles per perturbation step (wave 0): {(st[0] + st[1] + st[2] + st[3] + per_wave[5] + per_wave[6]) / st[6]:.0f}")
+if per_wave[5] > 0:
+    print(f"edge form, per step: latch / loop top {per_wave[5] / st[6]:.0f}, utility divisions (+ wait for the last move's loads) {per_wave[6] / st[6]:.0f}, "
+          f"arg-max reduction {st[0] / st[6]:.0f}, scans {st[1] / st[6]:.0f}, acceptance + reduction {st[2] / st[6]:.0f}, move {st[3] / st[6]:.0f}")
 print(f"descent: scans/iter {st[11] / it:.2f}; per scan: scan {st[8] / st[11]:.0f}, arg-min+wait {st[9] / st[11]:.0f}, "
       f"apply+barrier {st[10] / st[11]:.0f} cycles (share of descent {100 * (st[8] + st[9] + st[10]) / max(st[5], 1):.0f}%)")
 sc = max(st[11], 1)

@@ -27,7 +27,8 @@ def test_bench_single_rank_small():
     assert 64 / 1.5 < j["value"] < 64 / 0.45
     r = j["roofline"]
     # the committed counters are the headline's (TSP100 x 1024): for this 64-instance run the fractions are withheld, not borrowed
-    assert r["kernel"] == "gls_kernel" and r["bound"] == "valu_issue" and r["frac"] is None and not r["pmc_matches_workload"]
+    assert r["kernel"] == "gls_kernel" and r["bound"] == "latency" and "no PMC pass" in r["bound_source"] and r["frac"] is None and not r["pmc_matches_workload"]
+    assert r["critical_path"] is None                       # 64 instances run on the LDS-penalty store: no counting instantiation, no cycle records
     assert r["pmc"]["workload"] == {"n": 100, "instances": 1024, "guide": "model"} and r["binding_resource"]["name"] is None
     assert r["launches"] == 1 and j["config"]["rounds_per_rank"] == [1]
     # 64 instances run on the LDS-penalty store, which has no counting instantiation: the line says so instead of guessing
@@ -43,6 +44,9 @@ def test_bench_single_rank_small():
     q = j["iso_quality"]
     assert q["rounds"] == 10 and q["instances"] == 640 and q["budget"] == "per_batch"
     assert 640 / 1.6 < q["instances_per_s"] < 640 / 0.45 and q["mean_gap_pct"] >= j["mean_gap_pct"] - 1e-9
+    f = q["frontier"]                                        # the same loads inside the full limit, a third and a tenth of it
+    assert [round(p["time_limit_s"], 6) for p in f] == [0.5, round(0.5 / 3, 6), 0.05] and f[0]["instances_per_s"] == q["instances_per_s"]
+    assert all(0 < p["forward_share"] <= 1.2 and p["instances"] == 640 for p in f) and f[2]["instances_per_s"] > f[0]["instances_per_s"]
     assert j["config"]["residency_utilisation"] == [64 / 1024] and j["config"]["backend"] is None
     w = j["cpu_baseline"]["whole_box_estimate"]
     assert w["physical_cores"] >= 1 and w["instances_per_s"] > 0 and w["gpu_over_whole_box"] > 0

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_queries(lib):
-    assert lib.gnngls_abi_version() == 2
+    assert lib.gnngls_abi_version() == 3
     assert lib.gnngls_gls_resident_capacity(2) == 0
     caps = [lib.gnngls_gls_resident_capacity(n) for n in (20, 50, 100, 150)]
     assert all(c > 0 for c in caps) and caps == sorted(caps, reverse=True)
@@ -93,12 +93,21 @@ def test_gls_store_selection(lib):
     assert c == {"store": "compact", "threads": 256, "lds_bytes": 40960, "per_cu": 4, "team": False, "waves_per_simd": 4}
     # perturbation phase on all wavefronts only where every workgroup of the batch owns a CU (B <= 256 CUs) and is a
     # 16-wave workgroup (one per CU by its LDS footprint: n >= 144)
-    t200 = ops.gls_describe_config(200, 256)
+    # round 5: ... and only for first-improvement runs (best improvement: the edge form of the serial phase is faster there too)
+    t200 = ops.gls_describe_config(200, 256, first_improvement=True)
     assert t200["store"] == "compact" and t200["team"] and t200["threads"] == 1024 and t200["lds_bytes"] <= 160 * 1024
-    assert not ops.gls_describe_config(200, 257)["team"] and not ops.gls_describe_config(50, 128)["team"]
-    assert not ops.gls_describe_config(100, 256)["team"] and not ops.gls_describe_config(130, 8)["team"]
-    assert ops.gls_describe_config(150, 8, penalty_bits=-2)["team"] and not ops.gls_describe_config(160, 200)["team"]   # 8-wave LDS-penalty store
-    assert not ops.gls_describe_config(100, 128, penalty_bits=16)["team"] and not ops.gls_describe_config(300, 8)["team"]
+    b200 = ops.gls_describe_run(200, 256)
+    assert b200["store"] == "compact" and not b200["team"] and b200["edge_form"] and b200["threads"] == 1024 and b200["waves_per_simd"] == 4
+    assert not ops.gls_describe_run(200, 256, first_improvement=True)["edge_form"]
+    assert ops.gls_describe_run(100, 1024)["edge_form"] and ops.gls_describe_run(20, 1000)["edge_form"] and ops.gls_describe_run(50, 128)["edge_form"]
+    assert not ops.gls_describe_run(100, 700, penalty_bits=16)["edge_form"] and not ops.gls_describe_run(300, 8)["edge_form"]
+    fi = dict(first_improvement=True)
+    assert not ops.gls_describe_config(200, 257, **fi)["team"] and not ops.gls_describe_config(50, 128, **fi)["team"]
+    assert not ops.gls_describe_config(100, 256, **fi)["team"] and not ops.gls_describe_config(130, 8, **fi)["team"]
+    assert ops.gls_describe_config(150, 8, penalty_bits=-2, **fi)["team"] and not ops.gls_describe_config(160, 200, **fi)["team"]   # 8-wave LDS-penalty store
+    assert not ops.gls_describe_config(100, 128, penalty_bits=16, **fi)["team"] and not ops.gls_describe_config(300, 8, **fi)["team"]
+    # the launch-accurate query follows first_improvement where the older three answer for a best-improvement run
+    assert ops.gls_describe_run(30, 1000)["threads"] == 64 and ops.gls_describe_run(30, 1000, first_improvement=True)["threads"] == 128
     assert ops.gls_resident_capacity(100) == 1024 and ops.gls_resident_capacity(50) == 2048
     assert ops.gls_describe_config(50, 1024)["per_cu"] >= 4 and ops.gls_describe_config(50, 2048)["per_cu"] == 8
     assert ops.gls_describe_config(20, 1000)["threads"] == 64 and ops.gls_describe_config(20, 1000)["per_cu"] >= 4

@@ -15,6 +15,15 @@ def make_case(rng, n, kind):
     elif kind == "lattice":                       # many exact ties and zero deltas
         pos = rng.integers(0, 6, size=(n, 2)).astype(np.float64)
         D = np.abs(pos[:, None] - pos[None]).sum(-1) + 1.0
+    elif kind == "nonmetric":                     # round 5: uniform random symmetric matrix, no triangle inequality
+        D = rng.random((n, n)) * 10.0
+    elif kind == "negative":                      # symmetric with negative entries (operators.py:32-50,129-147 accept any matrix);
+        # the mean stays positive: with a negative start-tour length k = 0.1 cost / n is negative, penalties make edges CHEAPER
+        # and the reference's `while moves < perturbation_moves` (algorithms.py:150) never ends -- in the reference itself
+        D = rng.normal(1.0, 0.6, size=(n, n))
+    elif kind == "huge":                          # |D| > 1e6: the pruned scans' magnitude bound fails (prune_ok = 0: full scans run)
+        pos = rng.random((n, 2)) * 1e7
+        D = np.sqrt(((pos[:, None] - pos[None]) ** 2).sum(-1))
     else:                                         # lattice + noise around np.isclose's 1e-8 threshold
         pos = rng.integers(0, 4, size=(n, 2)).astype(np.float64)
         D = np.abs(pos[:, None] - pos[None]).sum(-1) + 1.0
@@ -40,6 +49,15 @@ for _ in range(14):
     CASES.append(dict(n=int(_rng2.integers(120, 256)), kind=str(_rng2.choice(["euclid", "lattice", "noisy"])),
                       pm=int(_rng2.choice([5, 20])), fi=bool(_rng2.integers(0, 2)), K=int(_rng2.integers(1, 3)),
                       bits=int(_rng2.choice([0, -2])), guides=int(_rng2.integers(1, 3)), seed=int(_rng2.integers(1 << 30))))
+
+
+# round 5: the pruned descent scans (n >= 80) and the edge form of the perturbation phase on matrices that are not
+# distances -- non-metric, negative entries, magnitudes beyond the pruning argument's bound
+_rng3 = np.random.default_rng(13579)
+for _k in ["nonmetric", "negative", "huge"] * 4:
+    CASES.append(dict(n=int(_rng3.integers(80, 256)), kind=_k, pm=int(_rng3.choice([5, 20])), fi=bool(_rng3.integers(0, 4) == 0),
+                      K=int(_rng3.integers(1, 3)), bits=int(_rng3.choice([0, -2])), guides=int(_rng3.integers(1, 3)),
+                      seed=int(_rng3.integers(1 << 30))))
 
 
 VARIANTS = {"serial": (0, 1), "team": (1, 1), "fullscan": (0, 0)}     # (team form of the perturbation phase, pruned descent scans)
@@ -68,7 +86,7 @@ def test_fuzz_case(c, variant):
     init = ops.nearest_neighbor(gd[0].contiguous())
     cost = ops.tour_cost(init, d)
     with ops.gls_team_mode(team), ops.gls_prune_mode(prune):
-        cfg = ops.gls_describe_config(n, B, c["bits"])
+        cfg = ops.gls_describe_config(n, B, c["bits"], first_improvement=c["fi"])
         assert cfg["team"] == (bool(team) and cfg["store"] != "global")          # n > ~200: the triangles leave the LDS
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=c["pm"], first_improvement=c["fi"], max_outer_iters=c["K"],
                         trace_cap=1 << 13, want_penalty=True, penalty_bits=c["bits"])
@@ -127,3 +145,31 @@ def test_local_search_mirror_rejects_asymmetric():
     D = np.random.default_rng(0).random((6, 6))
     with pytest.raises(NotImplementedError):
         alg.local_search([0, 1, 2, 3, 4, 5, 0], 1.0, D)
+
+
+@pytest.mark.parametrize("n,bits", [(12, 0), (50, 0), (100, -2), (150, 0), (200, -2)])
+def test_asymmetric_matrix_is_flagged_never_searched_silently(n, bits):
+    """The symmetric stores keep D[max, min] only.  An instance whose matrix differs from its transpose by one ulp in ONE entry
+    comes back with GNNGLS_STATUS_ASYMMETRIC, untouched (C ABI: never a silent different search); ops.gls_run reruns it on the
+    global-memory store, whose result is what that store gives for the whole batch (the reference's index order)."""
+    from gnngls_amd import ops
+    rng = np.random.default_rng(n)
+    B = 3
+    Ds, Gs = zip(*[make_case(rng, n, "euclid") for _ in range(B)])
+    D = np.stack(Ds)
+    D[1, 2, 1] = np.nextafter(D[1, 2, 1], np.inf)                  # instance 1: D[2,1] != D[1,2] by one ulp
+    guides = np.stack([np.stack(Gs)])
+    d, gd = torch.from_numpy(D).cuda(), torch.from_numpy(np.ascontiguousarray(guides)).cuda()
+    init = ops.nearest_neighbor(gd[0].contiguous())
+    cost = ops.tour_cost(init, d)
+    assert ops.gls_describe_config(n, B, bits)["store"] != "global"
+    raw = ops.gls_run(d, gd, init, cost, max_outer_iters=2, penalty_bits=bits, retry_asymmetric=False, want_penalty=True, imp_cap=8)
+    assert raw.status.cpu().tolist() == [0, ops.STATUS_ASYMMETRIC, 0]
+    assert torch.equal(raw.best_tour[1], init[1]) and raw.best_cost[1].item() == cost[1].item()
+    assert int(raw.outer_iters[1]) == 0 and int(raw.evals[1]) == 0 and int(raw.penalty[1].abs().sum()) == 0 and int(raw.imp_len[1]) == 0
+    auto = ops.gls_run(d, gd, init, cost, max_outer_iters=2, penalty_bits=bits, want_penalty=True)
+    glob = ops.gls_run(d, gd, init, cost, max_outer_iters=2, penalty_bits=-1, want_penalty=True)
+    assert auto.status.cpu().tolist() == [0, 0, 0] and glob.status.cpu().tolist() == [0, 0, 0]
+    for name in ("best_tour", "best_cost", "outer_iters", "evals", "penalty"):
+        assert torch.equal(getattr(auto, name), getattr(glob, name)), name
+    assert int(auto.outer_iters[1]) == 2

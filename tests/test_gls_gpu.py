@@ -207,12 +207,15 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
     improvement modes: every accepted move, the best tour / cost, the final penalties, the evaluation count and the
     improvement record equal the CPU oracle's bit for bit."""
     from oracle import gls_oracle as go
-    cfg = ops.gls_describe_config(n, B, penalty_bits=bits)
+    cfg = ops.gls_describe_config(n, B, penalty_bits=bits, first_improvement=fi)
     assert cfg["store"] == store and cfg["per_cu"] == per_cu and cfg["lds_bytes"] > 64 * 1024, cfg
-    policy_team = cfg["store"] == "compact" and cfg["threads"] == 1024      # 16-wave workgroup that owns its CU, B <= number of CUs
+    # 16-wave workgroup that owns its CU, B <= number of CUs; round 5: first-improvement runs only (best improvement runs the
+    # serial phase in its edge form, which is faster there too)
+    policy_team = cfg["store"] == "compact" and cfg["threads"] == 1024 and fi
     assert cfg["team"] == policy_team
-    c200 = ops.gls_describe_config(200, 256)
+    c200 = ops.gls_describe_config(200, 256, first_improvement=True)
     assert c200["store"] == "compact" and c200["team"] and c200["threads"] == 1024 and c200["lds_bytes"] <= 160 * 1024
+    assert not ops.gls_describe_config(200, 256)["team"] and ops.gls_describe_run(200, 256)["edge_form"]
     rng = np.random.default_rng(4000 + n)
     D, _ = random_instances(rng, B, n)
     guide = np.maximum(rng.normal(0.05, 0.1, size=D.shape).astype(np.float32).astype(np.float64), 0)
@@ -223,7 +226,7 @@ def test_gls_large_n_lds_stores_vs_oracle(ops, n, B, K, bits, store, per_cu, fi,
     init = ops.nearest_neighbor(gd[0])
     cost = ops.tour_cost(init, d)
     with ops.gls_team_mode(team), ops.gls_prune_mode(prune):
-        assert ops.gls_describe_config(n, B, penalty_bits=bits)["team"] == (team != 0 and policy_team)
+        assert ops.gls_describe_config(n, B, penalty_bits=bits, first_improvement=fi)["team"] == (team != 0 and policy_team)
         r = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,
                         trace_cap=1 << 14, want_penalty=True, imp_cap=32, penalty_bits=bits)
         plain = ops.gls_run(d, gd, init, cost, perturbation_moves=20, first_improvement=fi, max_outer_iters=K,

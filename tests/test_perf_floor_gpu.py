@@ -1,0 +1,43 @@
+"""Speed floors of the search kernel on the BASELINE.json shapes (round-4 review item 5): gls_kernels.hip is ~70 template
+instantiations whose code generation moves with unrelated edits; a regression there changes no result, so the parity tests
+cannot see it.  One second of search per shape with the bench's own guide (regret_pred of the synthetic model): the mean outer
+iterations must reach 85 % of the committed rate (profiles/r05_iteration_rates.json, same probe on the round's GPU boxes; box to
+box the rate moves by a few percent, a fall-back to the round-4 code paths costs 15-27 %), and the instantiation each shape runs
+on must have no scratch (TSP200: a bounded amount outside the loops)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RATES = json.load(open(os.path.join(ROOT, "profiles", "r05_iteration_rates.json")))
+
+
+@pytest.mark.parametrize("shape", sorted(RATES["shapes"]))
+def test_iteration_rate_floor_and_no_scratch(shape):
+    from gnngls_amd import ops, pipeline
+    from gnngls_amd.synthetic import random_instances
+    spec = RATES["shapes"][shape]
+    n, B = spec["n"], spec["instances"]
+    res = ops.gls_kernel_resources(n, B)
+    run = ops.gls_describe_run(n, B)
+    # one or two register slots per lane (n <= 127): no scratch at all.  Four slots (TSP200): the edge form keeps 28 registers of
+    # tour-edge state per lane through the perturbation phase and the compiler parks ~25 long-lived values of the descent in
+    # scratch AROUND the phase (65 scratch instructions at region boundaries, none in a scan loop: profiles/r05_isa/README.md) --
+    # bounded here so that a spill inside the loops would show
+    assert res["scratch_bytes"] <= (0 if n <= 127 else 128) and run["waves_per_simd"] in (2, 4), (res, run)
+    assert run["edge_form"] and not run["team"]
+    D = torch.from_numpy(random_instances(np.random.default_rng(0), B, n)[0]).cuda()
+    R = pipeline.predict_regret(pipeline.synthetic_model(seed=1234), D, pipeline.Scalers.fit_weights(D))
+    init = ops.nearest_neighbor(R)
+    cost = ops.tour_cost(init, D)
+    g = R[None].contiguous()
+    torch.cuda.synchronize()
+    r = ops.gls_run(D, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=1.0)
+    torch.cuda.synchronize()
+    assert int(r.status.sum()) == 0
+    rate = float(r.outer_iters.double().mean())
+    assert rate >= 0.85 * spec["outer_iters_per_s"], f"{shape}: {rate:.0f} outer iterations in 1 s, committed {spec['outer_iters_per_s']:.0f}"
