@@ -77,9 +77,6 @@ namespace gnngls {
 #ifndef GLS_SKIP_DEAD_PASS
 #define GLS_SKIP_DEAD_PASS 1         // pruned descent scans: a wavefront without rows in a pass skips it
 #endif
-#ifndef GLS_LEAN_SCALAR_TEST
-#define GLS_LEAN_SCALAR_TEST 0          // lean descent scans: scalar branch on a wave-wide test instead of an exec-masked one per step (A/B)
-#endif
 #ifndef GLS_LEAN_UNROLL
 #define GLS_LEAN_UNROLL 4            // evaluations per group in the lean descent scans (loads of a group issued up front)
 #endif
@@ -860,19 +857,11 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             delta = delta + vd;                              // +D[d,b]
             delta = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
-#if GLS_LEAN_SCALAR_TEST
-            // one scalar branch on "some lane beats its best" (an exec-masked region costs ~45 cycles even when it skips nothing:
-            // profiles/r05_isa/); the per-lane test only behind it
-            if (__builtin_amdgcn_ballot_w64(delta < bd) != 0ull) {
-                if (delta < bd && (unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
-            }
-#else
             if (delta < bd) {
                 rare_path();
                 // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
                 if ((unsigned)(kk - i + 2) > 2u && !close_to_zero(delta)) { bd = delta; bk = make_key(i, kk < i ? kk + 1 : kk); }
             }
-#endif
         }
     };
     using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
@@ -939,16 +928,10 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
             delta = delta - eab;
             delta = delta - ecd[u];
-#if GLS_LEAN_SCALAR_TEST
-            if (__builtin_amdgcn_ballot_w64(delta < bd) != 0ull) {
-                if (delta < bd && j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
-            }
-#else
             if (delta < bd) {                                // j < i + 2 holds the mirrored move's delta: rarely below the best either
                 rare_path();
                 if (j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }
             }
-#endif
         }
     };
     using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;

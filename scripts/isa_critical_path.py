@@ -95,7 +95,7 @@ def main():
     out = {"tsp100": {
         "instantiation": "gls_kernel<TriDGlobalP,false,2,false,4,false,false> (TSP100 x 1024, compact store, two register slots per lane)",
         "instructions_per_step": total_ins, "issue_cycles_per_step": total_cyc, "exposed_memory_cycles_per_step": exposed,
-        "issue_floor_cycles_per_step": total_cyc + exposed, "chain_floor_cycles_per_step": chain,
+        "issue_model_cycles_per_step": total_cyc + exposed, "chain_floor_cycles_per_step": chain,
         "stamped_cycles_per_step_diagnostic_build": 5308,
         "blocks": rows, "exposed": [{"what": w, "per_step": m, "cycles_each": c} for w, m, c in EXPOSED],
         "chain": [{"stage": s, "per_step": m, "cycles_each": sum(c for _, c in items), "items": [{"what": w, "cycles": c} for w, c in items]}
@@ -107,7 +107,7 @@ def main():
     print(f"{'block':16s} {'x/step':>6s} {'instr/step':>10s} {'cycles/step':>11s}  what")
     for r in rows:
         print(f"{r['block']:16s} {r['per_step']:6.1f} {r['instructions_per_step']:10.1f} {r['issue_cycles_per_step']:11.0f}  {r['what']}")
-    print(f"{'sum':16s} {'':6s} {total_ins:10.1f} {total_cyc:11.0f}  + exposed memory round trips {exposed:.0f} = issue floor {total_cyc + exposed:.0f} cycles per step")
+    print(f"{'sum':16s} {'':6s} {total_ins:10.1f} {total_cyc:11.0f}  + exposed memory round trips {exposed:.0f} = issue model {total_cyc + exposed:.0f} cycles per step")
     print()
     for s, m, items in CHAIN:
         print(f"chain: {s:24s} x{m:3.1f}  {sum(c for _, c in items):6.0f} cycles each: " + ", ".join(f"{w} {c:.0f}" for w, c in items))

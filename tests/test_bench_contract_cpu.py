@@ -48,10 +48,25 @@ def test_roofline_and_cpu_baseline_objects():
     if r["bound"] == "lds":                                        # lines of rounds 1-3: the algorithmic LDS figure only
         assert r["unit"] == "GB/s" and r["peak"] == 150000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     else:
-        assert r["bound"] == "valu_issue" and r["unit"] == "G SIMD-cycles/s"
         pmc = r["pmc"]
-        assert abs(r["frac"] - pmc["valu_busy_frac"]) < 1e-12 and 0 < r["frac"] <= 1
-        assert abs(r["peak"] - 1024 * pmc["clock_ghz"]) < 1e-9 * r["peak"] and abs(r["achieved"] - r["frac"] * r["peak"]) < 1e-9 * r["peak"]
+        if "critical_path" in r:
+            # round 5: the primary fraction is MEASURED in the run -- penalty steps per second of an instance against the rate the
+            # dependent chain of a step allows (committed chain floor / measured cycles per step) -- and `bound` is derived from
+            # the counters: no pipe above 60 % busy while the wavefronts wait for more than half of their cycles = "latency"
+            cp = r["critical_path"]
+            assert r["unit"] == "penalty steps/s per instance" and "measured in this run" in r["frac_source"]
+            assert abs(r["frac"] - cp["floor_cycles"] / cp["measured_cycles"]) < 1e-9 and 0 < r["frac"] <= 1
+            assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["achieved"] - cp["clock_ghz"] * 1e9 / cp["measured_cycles"]) < 1e-6 * r["achieved"]
+            assert 1.5 < cp["clock_ghz"] < 2.5 and 10 < cp["penalty_steps_per_outer_iteration"] < 25 and 0.2 < cp["share_of_kernel_cycles"] < 0.8
+            committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa", "critical_path.json")))["tsp%d" % j["config"]["n"]]
+            assert cp["floor_cycles"] == committed["chain_floor_cycles_per_step"] and cp.get("issue_model_cycles", cp.get("issue_floor_cycles")) == committed["issue_model_cycles_per_step"]
+            busiest = max(v for k, v in pmc.items() if k.endswith("_busy_frac"))
+            assert r["bound"] == ("latency" if busiest <= 0.6 and pmc["wave_wait_frac"] > 0.5 else r["binding_resource"]["name"])
+            assert "PMC counters" in r["bound_source"]
+        else:
+            assert r["bound"] == "valu_issue" and r["unit"] == "G SIMD-cycles/s"
+            assert abs(r["frac"] - pmc["valu_busy_frac"]) < 1e-12 and 0 < r["frac"] <= 1
+            assert abs(r["peak"] - 1024 * pmc["clock_ghz"]) < 1e-9 * r["peak"] and abs(r["achieved"] - r["frac"] * r["peak"]) < 1e-9 * r["peak"]
         # the counters were collected on the workload of the line itself
         assert r["pmc_matches_workload"] and pmc["workload"]["n"] == j["config"]["n"] and pmc["workload"]["guide"] == "model"
         # live part: executed <= reference-equivalent evaluations; LDS bytes of the executed ones against the aggregate rate
@@ -73,6 +88,14 @@ def test_roofline_and_cpu_baseline_objects():
         q = j["iso_quality"]
         assert q["budget"] == "per_batch" and q["rounds"] >= 2 and abs(q["instances_per_s"] - q["instances"] / q["wall_s"]) < 1e-9 * q["instances_per_s"]
         assert q["wall_s"] < 1.1 * q["time_limit_s"] + 1.0 and q["instances_per_s"] > 2 * j["value"]
+        if "frontier" in q:                                       # round 5: the same loads inside the full limit, a third, a tenth
+            f = q["frontier"]
+            assert len(f) == 3 and f[0]["instances_per_s"] == q["instances_per_s"] and all(0 < p["forward_share"] < 1.2 for p in f)
+            assert f[0]["instances_per_s"] < f[1]["instances_per_s"] < f[2]["instances_per_s"]
+            assert f[0]["mean_gap_pct"] <= f[1]["mean_gap_pct"] <= f[2]["mean_gap_pct"]
+        if j.get("true_gap_exact_sample"):                        # gap against PROVEN optima (branch and bound, checker side)
+            e = j["true_gap_exact_sample"]
+            assert e["instances"] >= 64 and e["mean_gap_pct"] >= -1e-9 and "bench_data/exact_optima" in e["source"]
         w = j["cpu_baseline"]["whole_box_estimate"]
         assert abs(w["instances_per_s"] - j["cpu_baseline"]["per_core_value"] * w["physical_cores"]) < 1e-9 * w["instances_per_s"]
         assert abs(w["gpu_over_whole_box"] - j["value"] / w["instances_per_s"]) < 1e-9 * w["gpu_over_whole_box"]
@@ -112,7 +135,16 @@ def test_search_roofline_object_is_self_consistent():
     traffic = {"valu_busy_frac": 0.6, "lds_busy_frac": 0.7, "clock_ghz": 2.0, "hbm_bytes_per_instance_second": 10.0,
                "workload": {"n": 100, "instances": 1024, "guide": "model"}}
     r = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, traffic, {"n": 100, "instances": 1024, "guide": "model"})
-    assert r["frac"] == 0.6 and r["peak"] == 2048.0 and abs(r["achieved"] - 0.6 * 2048.0) < 1e-9
+    assert r["frac"] == 0.6 and r["peak"] == 2048.0 and abs(r["achieved"] - 0.6 * 2048.0) < 1e-9      # no cycle records: the committed counter
+    assert "committed PMC pass" in r["frac_source"] and r["bound"] == "lds_issue" and r["critical_path"] is None
+    cyc = {"kernel_cycles": np.array([2e9, 2e9]), "pert_cycles": np.array([8e8, 8e8]), "steps": np.array([1.6e5, 1.6e5]),
+           "ticks": np.array([1e8, 1e8]), "outer_iters": np.array([9000., 9000.])}
+    lat = dict(traffic, valu_busy_frac=0.55, lds_busy_frac=0.3, wave_wait_frac=0.65)
+    rc = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, lat, {"n": 100, "instances": 1024, "guide": "model"}, cyc)
+    cp = rc["critical_path"]
+    assert rc["bound"] == "latency" and cp["measured_cycles"] == 5000.0 and abs(cp["clock_ghz"] - 2.0) < 1e-12
+    assert abs(rc["frac"] - cp["floor_cycles"] / 5000.0) < 1e-12 and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-12
+    assert abs(cp["share_of_kernel_cycles"] - 0.4) < 1e-12 and abs(cp["penalty_steps_per_outer_iteration"] - 160000 / 9000) < 1e-9
     # 4 launches of 1 s over 2 steps -> 2 launches per step; the evaluation counts are one step's
     assert abs(r["reference_equivalent_evals_per_s"] - 4e9) < 1 and abs(r["executed_evals_per_s"] - 1e9) < 1 and r["prune_ratio"] == 0.25
     assert r["binding_resource"]["name"] == "lds_issue" and r["binding_resource"]["second"] == "valu"    # sorted, not hard-coded
