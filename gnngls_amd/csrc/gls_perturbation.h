@@ -438,6 +438,11 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
 #else
 #define ISA_MARK(name) do {} while (0)
 #endif
+#ifndef GLS_EDGE_PREFETCH
+#define GLS_EDGE_PREFETCH 0           // edge form: issue the NEXT scan's loads under the current scan's wait, speculatively.  Measured
+                                      // (profiles/r05_experiments/ab_edge_unrolled_and_prefetch.log, bit-exact): -1 % at TSP100 x 1024,
+                                      // -8 % at TSP20 / TSP50 against the same unrolled step without it -- off
+#endif
 #ifndef GLS_EDGE_PERTURB
 #define GLS_EDGE_PERTURB 1           // 0: the scan-by-scan serial form everywhere (A/B builds)
 #endif
@@ -603,25 +608,33 @@ __device__ __forceinline__ int argmax_first_pos(const double (&util)[GP], const 
     return r;
 }
 
-// One guided one-to-all scan at tour index i on the tour held by E: RELOC = false two_opt_o2a, true relocate_o2a.
-// ok[q] = the lanes of slot q with a valid move, delta[q] their deltas; returns the lanes (any slot) with a negative one.
+// One guided one-to-all scan at tour index i on the tour held by E: RELOC = false two_opt_o2a, true relocate_o2a -- in two
+// halves, so that the loads of the NEXT scan of a step can be issued under the wait of the current one (scan_issue: the
+// wave-uniform nodes by v_readlane, packed offsets, counter / distance loads; scan_finish: everything else).
+template <bool RELOC, int GP>
+struct ScanLoads { PairLoad x0[GP], x1[GP], xac; };
+
 template <bool RELOC, class S, int GP>
-__device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, const TourEdges<GP> &E, const int lane, const int i,
-                                                const lanemask_t (&nm)[GP], double (&delta)[GP], lanemask_t (&ok)[GP]) {
+__device__ __forceinline__ void scan_issue(const S &s, const TourEdges<GP> &E, const int i, ScanLoads<RELOC, GP> &L) {
     ISA_MARK("scan_issue");
     const int na = edge_bcast<GP>(E.u, i), nb = edge_bcast<GP>(E.u, i - 1);       // a = t[i], b = t[i-1]
     const int nar = 2 * na * (na - 1), nbr = 2 * nb * (nb - 1);
-    PairLoad x0[GP], x1[GP], xac;
     if (RELOC) {                                             // G[t[i-1], t[i+1]]: a wave-uniform pair
         const int nc = edge_bcast<GP>(E.v, i);
-        xac = pair_issue(s, uniform_pair_offset(nb, nc));
+        L.xac = pair_issue(s, uniform_pair_offset(nb, nc));
     }
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
-        x0[q] = pair_issue(s, pair_offset(na, nar, E.v[q], E.vr[q]));                           // G[t[i], t[k+1]]
-        x1[q] = RELOC ? pair_issue(s, pair_offset(na, nar, E.u[q], E.ur[q]))                    // G[t[i], t[k]]
-                      : pair_issue(s, pair_offset(nb, nbr, E.u[q], E.ur[q]));                   // G[t[i-1], t[k]]
+        L.x0[q] = pair_issue(s, pair_offset(na, nar, E.v[q], E.vr[q]));                         // G[t[i], t[k+1]]
+        L.x1[q] = RELOC ? pair_issue(s, pair_offset(na, nar, E.u[q], E.ur[q]))                  // G[t[i], t[k]]
+                        : pair_issue(s, pair_offset(nb, nbr, E.u[q], E.ur[q]));                 // G[t[i-1], t[k]]
     }
+}
+
+// ok[q] = the lanes of slot q with a valid move, delta[q] their deltas; returns the lanes (any slot) with a negative one.
+template <bool RELOC, int GP>
+__device__ __forceinline__ lanemask_t scan_finish(const double k, const TourEdges<GP> &E, const int lane, const int i,
+                                                  const lanemask_t (&nm)[GP], ScanLoads<RELOC, GP> &L, double (&delta)[GP], lanemask_t (&ok)[GP]) {
     ISA_MARK("scan_under_latency");
     // under the loads' latency: everything that does not need them -- the guided lengths of the tour edges (registers), the
     // scan's own edges (v_readlane), the subtrahends and validity masks of the lanes
@@ -649,18 +662,18 @@ __device__ __forceinline__ lanemask_t eval_scan(const S &s, const double k, cons
     // every load of the scan was issued before the first is consumed (cf. scan_two_opt_o2a_guided_rm)
     ISA_MARK("scan_wait_and_arith");
 #pragma unroll
-    for (int q = 0; q < GP; ++q) { pin(x0[q]); pin(x1[q]); asm volatile("" : "+v"(ge[q])); if (!RELOC) asm volatile("" : "+v"(s1[q]), "+v"(s2[q])); }
+    for (int q = 0; q < GP; ++q) { pin(L.x0[q]); pin(L.x1[q]); asm volatile("" : "+v"(ge[q])); if (!RELOC) asm volatile("" : "+v"(s1[q]), "+v"(s2[q])); }
     double base = 0.0;
     if (RELOC) {
-        pin(xac);
+        pin(L.xac);
         base = -gab;                                         // operators.py:97-99, left to right
         base = base - gbc;
-        base = base + guided(k, xac);
+        base = base + guided(k, L.xac);
     }
     lanemask_t neg = 0ull;
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
-        const double gav = guided(k, x0[q]), gxu = guided(k, x1[q]);
+        const double gav = guided(k, L.x0[q]), gxu = guided(k, L.x1[q]);
         double d;
         if (!RELOC) {
             // two_opt_o2a (operators.py:53-73), j = k + 1: c = t[j] = v, d = t[j-1] = u: ((G[a,c] + G[b,d]) - G[a,b]) - G[c,d]
@@ -732,30 +745,52 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
             }
             s.pen_store_byte_if(own, uniform_pair_offset(eu, ev), cnt);
         }
-        int i = bp;                                          // algorithms.py:169: the edge was read at positions bp, bp + 1
+        // The four scans of the step (scan = 2 endpoint + operator; algorithms.py:167-171), unrolled: each with its operator as a
+        // compile-time constant (against one loop body that selects the operator at run time: +1 % at TSP100 x 1024, +6 .. 9 % at
+        // TSP20 / TSP50 / TSP150).  GLS_EDGE_PREFETCH (off, see there): while a scan waits for its counters the loads of the scan
+        // BEHIND it are issued on the current tour and dropped if the scan moves; the result never depends on them.
+        constexpr bool kPrefetch = GLS_EDGE_PREFETCH && GP <= 2;
+        const int sc_lo = eu == 0 ? 2 : 0, sc_hi = ev == 0 ? 2 : 4;
         bool moved_this_step = false;
-#pragma unroll 1
-        for (int sc = eu == 0 ? 2 : 0; sc < (ev == 0 ? 2 : 4); ++sc) {      // scan = 2 endpoint + operator; algorithms.py:167-171
-            ISA_MARK("scan_loop_head");
-            if (sc == 2) {                                   // endpoint 1: cur_tour.index(ev), searched only after a move
-                i = bp + 1;
-                if (moved_this_step) {
+        ScanLoads<false, GP> LT;
+        ScanLoads<true, GP> LR;
+        bool ahead = false;                                  // the loads of the scan about to run are already in flight
+        // index of endpoint 1: bp + 1 (algorithms.py:169: the edge was read at positions bp, bp + 1); cur_tour.index(ev), searched
+        // only after a move
+        auto index_of_ev = [&]() {
+            int i1 = bp + 1;
+            if (moved_this_step) {
 #pragma unroll
-                    for (int q = GP - 1; q >= 0; --q) {
-                        const lanemask_t m = nm0[q] & __builtin_amdgcn_ballot_w64(E.u[q] == ev);
-                        if (m) i = q * kWave + __ffsll((long long)m) - 1;
-                    }
+                for (int q = GP - 1; q >= 0; --q) {
+                    const lanemask_t m = nm0[q] & __builtin_amdgcn_ballot_w64(E.u[q] == ev);
+                    if (m) i1 = q * kWave + __ffsll((long long)m) - 1;
+                }
+            }
+            return i1;
+        };
+        int i = bp;
+        auto one_scan = [&](auto reloc_tag, const int sc) {
+            constexpr bool RELOC = decltype(reloc_tag)::value;
+            if (sc < sc_lo || sc >= sc_hi) return;
+            ISA_MARK("scan_loop_head");
+            if (sc == 2) i = index_of_ev();
+            auto &L = [&]() -> auto & { if constexpr (RELOC) return LR; else return LT; }();
+            if (!ahead) scan_issue<RELOC>(s, E, i, L);
+            ahead = false;
+            if constexpr (kPrefetch) {
+                if (sc + 1 < sc_hi) {                        // the next scan: the other operator; endpoint 1 after scan 1
+                    const int i_next = sc == 1 ? index_of_ev() : i;
+                    if constexpr (RELOC) scan_issue<false>(s, E, i_next, LT); else scan_issue<true>(s, E, i_next, LR);
+                    ahead = true;
                 }
             }
             double delta[GP];
             lanemask_t ok[GP];
-            const bool reloc = (sc & 1) != 0;
-            const lanemask_t neg = reloc ? eval_scan<true, S, GP>(s, k, E, lane, i, nm0, delta, ok)
-                                         : eval_scan<false, S, GP>(s, k, E, lane, i, nm2, delta, ok);
+            const lanemask_t neg = RELOC ? scan_finish<RELOC>(k, E, lane, i, nm0, L, delta, ok) : scan_finish<RELOC>(k, E, lane, i, nm2, L, delta, ok);
             ISA_MARK("accept_fast");
-            if (reloc) scans_re += 1; else scans_to += 1;
+            if (RELOC) scans_re += 1; else scans_to += 1;
             STAMP_END(1);
-            if (neg == 0ull) continue;                       // no negative delta: no candidate (most scans)
+            if (neg == 0ull) return;                         // no negative delta: no candidate (most scans)
             ISA_MARK("accept_slow");
             // np.isclose evaluated literally; the keys of a lane ascend with its slots, so a strict < keeps the lane's first
             // minimum (operators.py:65,118)
@@ -764,19 +799,20 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
             for (int q = 0; q < GP; ++q) {
                 const double d = delta[q];
                 const int kk = lane + q * kWave;
-                const int key = reloc ? (kk >= i + 1 ? kk : kk + 1) : kk + 1;
+                const int key = RELOC ? (kk >= i + 1 ? kk : kk + 1) : kk + 1;
                 const lanemask_t take = ok[q] & __builtin_amdgcn_ballot_w64(d < bd) & ~__builtin_amdgcn_ballot_w64(close_to_zero(d));
                 bd = sel_f64(take, d, bd);
                 bk = sel_b32(take, key, bk);
             }
-            if (__builtin_amdgcn_ballot_w64(bk != kNoKey) == 0ull) { STAMP_END(2); continue; }
+            if (__builtin_amdgcn_ballot_w64(bk != kNoKey) == 0ull) { STAMP_END(2); return; }
             wave_reduce_best<false>(bd, bk);
             bk = __builtin_amdgcn_readfirstlane(bk);
             STAMP_END(2);
             ISA_MARK("move");
-            edges_move(s, E, t, t2, guide, n, sc & 1, i, bk, lane);          // algorithms.py:175-177
+            edges_move(s, E, t, t2, guide, n, RELOC ? 1 : 0, i, bk, lane);     // algorithms.py:175-177
             { TT *x = t; t = t2; t2 = x; }
             any_moved = true; moved_this_step = true;
+            ahead = false;                                   // what was issued ahead was on the old tour
             moves += 1;                                      // algorithms.py:185
             if (eager_cost) {
 #pragma unroll
@@ -787,7 +823,11 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
             }
             STAMP_END(3);
             ISA_MARK("scan_loop_tail");
-        }
+        };
+        one_scan(std::false_type{}, 0);
+        one_scan(std::true_type{}, 1);
+        one_scan(std::false_type{}, 2);
+        one_scan(std::true_type{}, 3);
         ISA_MARK("step_tail");
         steps++;
         STAMP_COUNT(6);
