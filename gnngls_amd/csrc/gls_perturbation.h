@@ -566,9 +566,17 @@ __device__ __forceinline__ void edges_move(const S &s, TourEdges<GP> &E, const T
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
         const int p = lane + q * kWave, pc = p < n ? p : 0;
-        const int u = told[move_src_flat(mm, pc)], v = told[move_src_flat(mm, pc + 1)];
-        E.u[q] = u; E.v[q] = v;
+        const int u = told[move_src_flat(mm, pc)];
+        E.u[q] = u;
         tnew[pc] = (TT)u;
+    }
+    // v = the node of the NEXT position = u of the next lane (DPP wave_shl:1; lane 63 takes lane 0 of the next slot; behind the
+    // tour every lane holds the depot, which is also what closes the tour): no second source position, no second LDS read
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        int v = __builtin_amdgcn_update_dpp(0, E.u[q], 0x130, 0xf, 0xf, false);
+        if (q + 1 < GP) v = sel_b32(1ull << 63, __builtin_amdgcn_readlane(E.u[q + 1 < GP ? q + 1 : q], 0), v);
+        E.v[q] = v;
     }
     edges_fetch(s, E, guide, n);
 }
@@ -606,6 +614,21 @@ __device__ __forceinline__ int argmax_first_pos(const double (&util)[GP], const 
     const int r = (int)wave_umin((hi == mhi && lo == mlo) ? (unsigned)pos : 0x7fffffffu);
     ISA_MARK("argmax_reduce");
     return r;
+}
+
+// key of the lexicographic minimum of (delta, key) over the lanes with a candidate (key != kNoKey; their delta < 0): the wave
+// reduction of wave_min_value_key with a select-free order-preserving image (negative deltas only: the image of a negative
+// double is its complemented bit pattern) -- only the key is needed, the move's delta is not used by the perturbation phase
+__device__ __forceinline__ int wave_argmin_key(double d, int k) {
+    const long long b = __double_as_longlong(d);
+    const lanemask_t cand = __builtin_amdgcn_ballot_w64(k != kNoKey);
+    const unsigned hi = (unsigned)sel_b32(cand, ~(int)(b >> 32), -1), lo = ~(unsigned)b;
+    const unsigned mhi = wave_umin(hi);
+    const lanemask_t tie = cand & __builtin_amdgcn_ballot_w64(hi == mhi);
+    if ((tie & (tie - 1)) == 0ull) return __builtin_amdgcn_readlane(k, __ffsll((long long)tie) - 1);
+    const unsigned mlo = wave_umin((unsigned)sel_b32(tie, (int)lo, -1));
+    const lanemask_t tie2 = tie & __builtin_amdgcn_ballot_w64(lo == mlo);
+    return (int)wave_umin((unsigned)sel_b32(tie2, k, 0x7fffffff));
 }
 
 // One guided one-to-all scan at tour index i on the tour held by E: RELOC = false two_opt_o2a, true relocate_o2a -- in two
@@ -805,8 +828,7 @@ __device__ __forceinline__ void serial_perturbation_edges(const S &s, const doub
                 bk = sel_b32(take, key, bk);
             }
             if (__builtin_amdgcn_ballot_w64(bk != kNoKey) == 0ull) { STAMP_END(2); return; }
-            wave_reduce_best<false>(bd, bk);
-            bk = __builtin_amdgcn_readfirstlane(bk);
+            bk = wave_argmin_key(bd, bk);
             STAMP_END(2);
             ISA_MARK("move");
             edges_move(s, E, t, t2, guide, n, RELOC ? 1 : 0, i, bk, lane);     // algorithms.py:175-177
