@@ -24,23 +24,26 @@ COST = {"valu": 4.3, "salu": 4.6, "cndmask_sgpr": 4.3, "cndmask_vcc": 13.3, "rea
         "waitcnt": 1.0, "branch": 16.0, "lds": 4.5, "vmem": 4.5, "smem": 4.6, "other": 4.5}
 L2_ROUND_TRIP, LDS_ROUND_TRIP = 270.0, 64.0       # buffer_load_dword L2 hit / ds_read round trip, idle chip
 
-# block label -> (executions per penalty step, executed share of the block's instructions, what it is)
+# block label -> (executions per penalty step, executed share of the block's instructions, what it is).  The four scans of a step
+# are unrolled (one block each, with its acceptance code); "#slow" = the part of a scan block behind "some lane has a negative
+# delta" (np.isclose, per-lane strict <, DPP arg-min without its tie path: ~56 of the ~80 instructions of that side)
 PATH = {
-    ".LBB5_516": (1.0, 1.0, "loop top"),
-    ".LBB5_517": (1.0, 0.58, "arg-max: two fp64 divisions, key image, DPP min over the high words (the tie path, 42 % of the block, is rare)"),
-    ".LBB5_520": (1.0, 1.0, "arg-max: position of the single winner (s_ff1 + v_readlane)"),
-    ".LBB5_522": (1.0, 1.0, "penalise: (eu, ev) by v_readlane, counter + 1 by its owner lane, one buffer store"),
-    ".LBB5_526": (4.0, 1.0, "scan loop head (endpoint / operator selection)"),
-    ".LBB5_528": (2.0, 1.0, "two_opt_o2a scan: 2 slots x 2 guided values, uniform terms by v_readlane, deltas, negative-delta mask"),
-    ".LBB5_530": (2.0, 1.0, "relocate_o2a scan: the same + G[a,c] of a uniform pair"),
-    ".LBB5_532": (4.0, 0.12, "acceptance, fast side: one scalar test of the negative-delta mask"),
-    ".LBB5_532#slow": (1.2, 0.68, "acceptance, slow side: np.isclose, per-lane strict <, DPP arg-min (its tie path is rare)"),
-    ".LBB5_536": (1.2, 1.0, "arg-min: key of the single winner"),
-    ".LBB5_538": (1.2, 1.0, "move parameters (scalar)"), ".LBB5_541": (0.6, 1.0, "move parameters (scalar)"),
-    ".LBB5_543": (0.6, 1.0, "move parameters (scalar)"), ".LBB5_544": (1.2, 1.0, "move parameters (scalar)"),
-    ".LBB5_524": (1.2, 1.0, "move: new (u, v) of every edge from the old tour in LDS, new tour written, counter / distance / guide loads issued"),
-    ".LBB5_525": (4.0, 1.0, "scan loop latch"),
-    ".LBB5_546": (1.0, 1.0, "step tail"), ".LBB5_548": (1.0, 1.0, "step tail"),
+    ".LBB5_564": (1.0, 1.0, "step latch"), ".LBB5_515": (1.0, 1.0, "loop top"),
+    ".LBB5_516": (1.0, 0.58, "arg-max: two fp64 divisions, key image, DPP min over the high words (the tie path, 42 % of the block, is rare)"),
+    ".LBB5_519": (1.0, 1.0, "arg-max: position of the single winner (s_ff1 + v_readlane)"),
+    ".LBB5_521": (1.0, 0.646, "penalise (counter + 1 by its owner lane, one buffer store) + two_opt_o2a scan of endpoint 0 + acceptance, fast side"),
+    ".LBB5_521#slow": (0.93, 0.248, "acceptance of scan 0, slow side (the first scan accepts in 93 % of the steps)"),
+    ".LBB5_526": (0.93, 1.0, "arg-min: key of the single winner"),
+    ".LBB5_528": (0.93, 1.0, "move after scan 0: scalar move parameters, new (u, v) from the old tour in LDS + DPP neighbour, tour written, loads issued"),
+    ".LBB5_529": (0.07, 1.0, "scan 0 without a move"),
+    ".LBB5_531": (1.0, 0.626, "relocate_o2a scan of endpoint 0 (2 slots x 2 guided values + G[a,c] of a uniform pair) + acceptance, fast side"),
+    ".LBB5_531#slow": (0.06, 0.262, "acceptance of scan 1, slow side"), ".LBB5_535": (0.06, 1.0, "arg-min"), ".LBB5_537": (0.06, 1.0, "move after scan 1"),
+    ".LBB5_539": (1.0, 1.0, "endpoint 1: index"),
+    ".LBB5_542": (1.0, 0.59, "two_opt_o2a scan of endpoint 1 + acceptance, fast side"),
+    ".LBB5_542#slow": (0.15, 0.287, "acceptance of scan 2, slow side"), ".LBB5_546": (0.15, 1.0, "arg-min"), ".LBB5_548": (0.15, 1.0, "move after scan 2"),
+    ".LBB5_550": (1.0, 0.631, "relocate_o2a scan of endpoint 1 + acceptance, fast side"),
+    ".LBB5_550#slow": (0.06, 0.258, "acceptance of scan 3, slow side"), ".LBB5_555": (0.06, 1.0, "arg-min"), ".LBB5_557": (0.06, 1.0, "move after scan 3"),
+    ".LBB5_559": (1.0, 1.0, "step tail"), ".LBB5_561": (1.0, 1.0, "step tail"),
 }
 # exposed memory round trips per step (not covered by independent instructions of the same wavefront): per scan the LAST of its
 # loads is issued ~25 instructions (110 cycles) before the wait; per move one LDS round trip (the old tour's nodes)
@@ -96,7 +99,7 @@ def main():
         "instantiation": "gls_kernel<TriDGlobalP,false,2,false,4,false,false> (TSP100 x 1024, compact store, two register slots per lane)",
         "instructions_per_step": total_ins, "issue_cycles_per_step": total_cyc, "exposed_memory_cycles_per_step": exposed,
         "issue_model_cycles_per_step": total_cyc + exposed, "chain_floor_cycles_per_step": chain,
-        "stamped_cycles_per_step_diagnostic_build": 5308,
+        "measured_cycles_per_step_product_kernel_r05b": 4869,
         "blocks": rows, "exposed": [{"what": w, "per_step": m, "cycles_each": c} for w, m, c in EXPOSED],
         "chain": [{"stage": s, "per_step": m, "cycles_each": sum(c for _, c in items), "items": [{"what": w, "cycles": c} for w, c in items]}
                   for s, m, items in CHAIN],
