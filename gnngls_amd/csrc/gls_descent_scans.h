@@ -250,6 +250,31 @@ __device__ __forceinline__ void block_reduce_best_lds(Ctl *ctl, int &phase, int 
 // Measured (same box, outer iterations per instance in 2 s, TSP100 x 1024 noise / weight guide, TSP200 x 256, TSP50 x 128;
 // profiles/r02_ab_lean_scan_v2.log): select-free address 7.15k -> 7.46k / 11.96k -> 12.34k / 5.46k -> 5.61k / 9.96k -> 10.24k;
 // + edge lengths from LDS instead of two v_readlane 8.06k / 12.91k / 6.07k / 10.43k; + late validity 8.20k / 13.06k / 6.12k / 10.42k.
+// Round 5: the deltas of a group against the lane's best, all at once.  `delta < bd` can only hold for a step of the group if the
+// group's minimum is below bd (bd only falls inside a group; v_min_f64 returns the other operand for a NaN, and a NaN delta never
+// beats anything): a filter in front of the per-step tests, which run unchanged behind it -- one exec-masked region (v_cmp,
+// s_and_saveexec, s_cbranch_execz, s_or: four instructions and ~45 cycles of the wavefront, entered or not) per group instead of
+// one per step, for U - 1 v_min_f64.  Same-box A/B (profiles/r05_experiments/ab_descent_*.log, outer iterations per 2 s, TSP100 x
+// 1024, model guide): 22.40k -> 23.13k; with six steps per group in the relocate scan (GLS_LEAN_UNROLL_RELOCATE) 23.48k, TSP50 x 128
+// 27.80k -> 28.04k (six steps in the 2-opt scan too: 27.47k; eight: 26.2k).
+#ifndef GLS_LEAN_MINFILTER
+#define GLS_LEAN_MINFILTER 1
+#endif
+__device__ __forceinline__ double min_f64_raw(double a, double b) {      // (fmin puts a canonicalising v_max_f64 x, x in front of operands it cannot see through)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int LO, int HI, int U>
+__device__ __forceinline__ double min_tree(const double (&dl)[U]) {
+    if constexpr (HI - LO == 1) return dl[LO];
+    else return min_f64_raw(min_tree<LO, (LO + HI) / 2>(dl), min_tree<(LO + HI) / 2, HI>(dl));
+}
+template <int U>
+__device__ __forceinline__ bool group_may_improve(const double (&dl)[U], double bd) {
+    if constexpr (!GLS_LEAN_MINFILTER || U == 1) return true;
+    else return min_tree<0, U>(dl) < bd;
+}
 template <int SL>
 struct LaneTour {      // positions lane, lane + 64, ... (SL slots) of the tour in registers
     int t[SL];
@@ -364,13 +389,19 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             if constexpr (FA) ve[u] = lds_read_f64(tri_addr_max(bx, b8, dbase + 4 * e * (e - 1), 8 * e));   // 8 e(e-1)/2, no shift pair
             else ve[u] = s.dist_at(s.idx2(b, b2, e, e2));    // D[b, t[k+1]]
         }
+        double dl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double delta = base - de[u];                     // -D[d,e]          (operators.py:100-102, left to right)
+            delta = delta + vd;                              // +D[d,b]
+            dl[u] = delta + ve[u];                           // +D[b,e]
+            vd = ve[u];
+        }
+        if (!group_may_improve(dl, bd)) return;              // one exec-masked region per group instead of one per step
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = k + u;
-            double delta = base - de[u];                     // -D[d,e]          (operators.py:100-102, left to right)
-            delta = delta + vd;                              // +D[d,b]
-            delta = delta + ve[u];                           // +D[b,e]
-            vd = ve[u];
+            const double delta = dl[u];
             if (delta < bd) {
                 rare_path();
                 // valid targets: k <= i-3 (j = k+1 < i-1) or k >= i+1 (j = k); k in {i-2, i-1, i} <=> (unsigned)(k - i + 2) <= 2
@@ -378,7 +409,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_LEAN_UNROLL>;
+    using UN = std::integral_constant<int, GLS_LEAN_UNROLL_RELOCATE>;
     using U1 = std::integral_constant<int, 1>;
     using FAST = std::integral_constant<bool, true>;
     using EXACT = std::integral_constant<bool, false>;
@@ -388,7 +419,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
         const int lo = q * kWave - 1, hi = q * kWave + kWave - 1;
         int k = k0 > lo ? k0 : lo;
         const int ke = k1f < hi ? k1f : hi;
-        for (; k + GLS_LEAN_UNROLL <= ke; k += GLS_LEAN_UNROLL) group(k, L.t[q], UN{}, FAST{});
+        for (; k + GLS_LEAN_UNROLL_RELOCATE <= ke; k += GLS_LEAN_UNROLL_RELOCATE) group(k, L.t[q], UN{}, FAST{});
         for (; k < ke; ++k) group(k, L.t[q], U1{}, FAST{});
     }
     if (k1f != k1) {                                         // keys ascend with k within a lane: the last step stays last
@@ -437,11 +468,17 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             vbd[u] = lds_read_f64(tri_addr_max(bx, b8, d2, 8 * d));      // D[b,d]
             d = c; d2 = c2;
         }
+        double dl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double delta = vac[u] + vbd[u];                  // operators.py:25-28, left to right
             delta = delta - eab;
-            delta = delta - ecd[u];
+            dl[u] = delta - ecd[u];
+        }
+        if (!group_may_improve(dl, bd)) return;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double delta = dl[u];
             if (delta < bd) {                                // j < i + 2 holds the mirrored move's delta: rarely below the best either
                 rare_path();
                 if (j + u >= i + 2 && !close_to_zero(delta)) { bd = delta; bk = make_key(i, j + u); }

@@ -447,20 +447,6 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
 #define GLS_EDGE_PERTURB 1           // 0: the scan-by-scan serial form everywhere (A/B builds)
 #endif
 
-typedef unsigned long long lanemask_t;
-// lane-wise m ? a : b with the condition in a scalar register pair (v_cndmask_b32 e64: 4.3 cycles; on VCC the same select
-// measures 8-17)
-__device__ __forceinline__ int sel_b32(lanemask_t m, int a, int b) {
-    int r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
-}
-__device__ __forceinline__ double sel_f64(lanemask_t m, double a, double b) {
-    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
-    const int lo = sel_b32(m, (int)ab, (int)bb), hi = sel_b32(m, (int)(ab >> 32), (int)(bb >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
 template <int GP>
 struct TourEdges {
     int u[GP], v[GP];                // nodes of tour edge p = lane + 64 q (lanes with p >= n hold edge 0: valid nodes, results masked)
