@@ -419,6 +419,18 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     const float *layers = emb_b + 128;
     const float *dec_w = layers + (long)n_layers * kLayerFloats, *dec_b = dec_w + 128;
     hipError_t e = hipSuccess;
+    // scratch for one layer's split weights (the bf16x3 form of the feed-forward block), stream-ordered like gls_run's;
+    // GNNGLS_FFN_FP32=1 keeps the block on the fp32 matrix pipe (A/B runs)
+    struct StreamScratch {
+        void *p = nullptr; hipStream_t st;
+        ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
+    } ffn_ws;
+    ffn_ws.st = st;
+    static const bool ffn_fp32 = getenv("GNNGLS_FFN_FP32") && atoi(getenv("GNNGLS_FFN_FP32")) != 0;
+    if (n_layers > 0 && !ffn_fp32) {
+        e = hipMallocAsync(&ffn_ws.p, gnngls::ffn_packed_bytes(), st);
+        if (e != hipSuccess) { ffn_ws.p = nullptr; return hip_fail(e, "regret_forward: scratch alloc"); }
+    }
 #define GNNGLS_TRY(x) do { e = (x); if (e != hipSuccess) return hip_fail(e, #x); } while (0)
     for (long b0 = 0; b0 < B; b0 += Bc) {
         const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
@@ -437,7 +449,7 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
             // gat_combine + FFN1 + FFN2 in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
-              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, st)); }
+              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, ffn_ws.p, st)); }
             { float *x = h; h = h2; h2 = x; }
         }
         { ProfScope ps(GNNGLS_PROF_DECISION, st);

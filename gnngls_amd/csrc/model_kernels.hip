@@ -742,6 +742,217 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same block on the bf16 matrix pipe with fp32 accuracy ("bf16x3 operands, six products").  CDNA4 runs
+// v_mfma_f32_16x16x32_bf16 at SIXTEEN times the fp32 MFMA rate (2.5 PFLOP/s against 157 TFLOP/s, and no xf32 form): an fp32
+// value is the sum of three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significand bits: x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1); bf16 has the fp32 exponent, so nothing over- or underflows), every piece product is exact in the
+// fp32 accumulator, and a b = a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0 + O(2^-23 |a b|): six MFMAs of K = 32 (96 cycles of
+// the matrix pipe) do the work of eight fp32 MFMAs of K = 4 (256 cycles) with the rounding error of fp32 arithmetic -- measured
+// against the fp64 oracle the block's error is that of the fp32 kernel (tests/test_model_gpu.py, unchanged 1e-5 bar; the numpy
+// model of both paths: 4.5e-7 against 4.8e-7 of max|y|; three products, i.e. two pieces, would be 6.5e-6).  Inference only; the
+// training kernels above stay on the fp32 pipe.
+// The weights are split and laid out in fragment order once per launch by ffn_pack_bf16x3_kernel (786 KB per layer, L2-resident):
+//     W1p[c][kb][ht][p][lane][8]   = piece p of W1[128 c + 16 ht + (lane & 15)][32 kb + 8 (lane >> 4) + e]
+//     W2p[c][j][ot][p][lane][8]    = piece p of W2[16 ot + (lane & 15)][128 c + 32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
+// so that a stage's 24 KB are a flat copy into LDS and a wavefront's A fragment is one conflict-free ds_read_b128.  The k order of
+// W2p is the accumulator layout of GEMM1 (lane (row, q) holds hidden units 16 ht + 4 q + r of its row): as in the fp32 kernel
+// the hidden layer goes from the accumulators of GEMM1 through ReLU and the split straight into the B operand of GEMM2.
+// One workgroup = 128 rows, 8 wavefronts of 16 rows (two per SIMD), one workgroup per CU (118 KB of LDS: the x tile in fp32 for the
+// skip connection, split on the fly per k block; two 24 KB weight stages).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int FB_M = 128;                          // rows per workgroup
+constexpr int FB_STAGE = 8 * 3 * 64 * 16;          // bytes of one weight stage: 8 tiles x 3 pieces x 64 lanes x 16 B
+constexpr size_t kFfnPackedBytes = (size_t)2 * 16 * FB_STAGE;      // W1p + W2p: 786,432 B
+
+__device__ __forceinline__ void split_bf16x3(const float (&x)[8], bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h0 = (__bf16)x[e];
+        const float r1 = x[e] - (float)h0;               // exact
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;                 // exact
+        p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+}
+// acc += a b with a = a0 + a1 + a2, b = b0 + b1 + b2 (the three products of order 2^-24 and below are dropped); small terms first
+__device__ __forceinline__ f32x4 mfma_bf16x3(const bf16x8 &a0, const bf16x8 &a1, const bf16x8 &a2, const bf16x8 &b0,
+                                             const bf16x8 &b1, const bf16x8 &b2, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+    return acc;
+}
+
+// one thread per (matrix, chunk, stage, tile, lane): the three pieces of its eight weights
+__global__ void ffn_pack_bf16x3_kernel(const float *__restrict__ W1, const float *__restrict__ W2, unsigned char *__restrict__ packed) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;             // 2 x 4 x 4 x 8 x 64 = 16384 threads
+    const int lane = g & 63, tile = (g >> 6) & 7, sub = (g >> 9) & 3, c = (g >> 11) & 3, second = g >> 13;
+    const int lr = lane & 15, lq = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        v[e] = second ? W2[(long)(tile * 16 + lr) * 512 + c * 128 + 32 * sub + 16 * (e >> 2) + 4 * lq + (e & 3)]
+                      : W1[(long)(c * 128 + tile * 16 + lr) * 128 + 32 * sub + 8 * lq + e];
+    bf16x8 p0, p1, p2;
+    split_bf16x3(v, p0, p1, p2);
+    unsigned char *dst = packed + (size_t)second * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE + (size_t)(tile * 3) * 1024 + lane * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = p0;
+    *reinterpret_cast<bf16x8 *>(dst + 1024) = p1;
+    *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
+}
+
+__global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
+                                                                  const float *__restrict__ hin,
+                                                                  const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
+                                                                  const unsigned char *__restrict__ packed, const float *__restrict__ b1,
+                                                                  const float *__restrict__ b2,
+                                                                  const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
+                                                                  float *__restrict__ hout, long M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
+    unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // two weight stages
+    unsigned char *Wb1 = Wb0 + FB_STAGE;
+    float *vecs = reinterpret_cast<float *>(Wb1 + FB_STAGE);                       // b1[512] b2[128] bn2_s[128] bn2_b[128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wrow = wave * 16;
+    const long row0 = (long)blockIdx.x * FB_M;
+
+    vecs[tid] = b1[tid];
+    if (tid < 128) { vecs[512 + tid] = b2[tid]; vecs[640 + tid] = bn2_s[tid]; vecs[768 + tid] = bn2_b[tid]; }
+
+    // ---- stage the x tile: x = BN1(h + merge(partials))  (gat_combine fused; models.py:15,24,28), as in ffn_fused_kernel ----
+    constexpr int PB = 4;
+    for (int it0 = 0; it0 < (FB_M * 32) / 512; it0 += PB) {
+        f32x4 p0[PB], p1[PB], hv[PB];
+        float m0[PB], s0[PB], m1[PB], s1[PB];
+        bool live[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int idx = (it0 + u) * 512 + tid;
+            const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
+            const long m = row0 + row;
+            live[u] = m < M;
+            const long mc = live[u] ? m : 0;
+            const float *ms0 = part_ms + mc * (2 * kH), *ms1 = part_ms + (M + mc) * (2 * kH);
+            m0[u] = ms0[hd]; s0[u] = ms0[kH + hd]; m1[u] = ms1[hd]; s1[u] = ms1[kH + hd];
+            p0[u] = *reinterpret_cast<const f32x4 *>(part + mc * kD + c);
+            p1[u] = *reinterpret_cast<const f32x4 *>(part + (M + mc) * kD + c);
+            hv[u] = *reinterpret_cast<const f32x4 *>(hin + mc * kD + c);
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int idx = (it0 + u) * 512 + tid;
+            const int row = idx >> 5, c = (idx & 31) * 4;
+            const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
+            const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
+            const float inv = 1.f / (s0[u] * a0 + s1[u] * a1);
+            f32x4 o4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float g = (p0[u][v] * a0 + p1[u][v] * a1) * inv;
+                const float o = (hv[u][v] + g) * bn1_s[c + v] + bn1_b[c + v];
+                o4[v] = live[u] ? o : 0.f;
+            }
+            *reinterpret_cast<f32x4 *>(Xs + row * LDX + c) = o4;
+        }
+    }
+
+    // ---- weight stage stream: stage t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1p, 1: W2p), sub = t&3; a flat 24 KB copy ----
+    f32x4 rw[3];
+    auto gload = [&](int t) {
+        const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
+        const unsigned char *src = packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE + tid * 16;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) rw[u] = *reinterpret_cast<const f32x4 *>(src + u * 8192);
+    };
+    auto lstore = [&](unsigned char *Wt) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4 *>(Wt + tid * 16 + u * 8192) = rw[u];
+    };
+    gload(0);
+    lstore(Wb0);
+    __syncthreads();
+
+    f32x4 accY[8], accH[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) accY[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto tiles = [&](f32x4 (&acc)[8], const unsigned char *Wt, const bf16x8 &b0, const bf16x8 &b1v, const bf16x8 &b2v) {
+#pragma unroll
+        for (int tl = 0; tl < 8; ++tl) {
+            const unsigned char *f = Wt + (size_t)(tl * 3) * 1024 + lane * 16;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(f);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+            acc[tl] = mfma_bf16x3(a0, a1, a2, b0, b1v, b2v, acc[tl]);
+        }
+    };
+
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        // hidden pre-activations start at the bias (C-in of the MFMA chain), models.py:30
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) accH[ht] = *reinterpret_cast<const f32x4 *>(vecs + c * 128 + ht * 16 + 4 * lq);
+#pragma unroll
+        for (int sub = 0; sub < 8; ++sub) {
+            const int t = c * 8 + sub;
+            if (t + 1 < 32) gload(t + 1);
+            const unsigned char *Wt = (sub & 1) ? Wb1 : Wb0;
+            float v[8];
+            if (sub < 4) {                               // GEMM1, k block `sub`: B = the pieces of x[row][32 sub + 8 q .. + 7]
+                const float *xp = Xs + (wrow + lr) * LDX + sub * 32 + 8 * lq;
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+            } else {                                     // GEMM2, hidden block j = sub - 4: B = the pieces of ReLU(hidden), models.py:31
+                const int j = sub - 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = accH[2 * j][e], u1 = accH[2 * j + 1][e];
+                    v[e] = u0 > 0.f ? u0 : 0.f; v[4 + e] = u1 > 0.f ? u1 : 0.f;
+                }
+            }
+            bf16x8 q0, q1, q2;
+            split_bf16x3(v, q0, q1, q2);
+            if (sub < 4) tiles(accH, Wt, q0, q1, q2);
+            else tiles(accY, Wt, q0, q1, q2);
+            if (t + 1 < 32) lstore((sub & 1) ? Wb0 : Wb1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: y = BN2(x + (acc + b2)); transposed accumulator -> x tile in LDS -> coalesced rows ----
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        const int out = ot * 16 + 4 * lq;
+        float *xp = Xs + (wrow + lr) * LDX + out;
+        f32x4 x = *reinterpret_cast<const f32x4 *>(xp);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(vecs + 512 + out);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(vecs + 640 + out);
+        const f32x4 sh = *reinterpret_cast<const f32x4 *>(vecs + 768 + out);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = accY[ot][r] + bb[r];            // Linear2 output (models.py:32)
+            v = x[r] + v;                             // x + y            (models.py:15)
+            x[r] = v * sc[r] + sh[r];                 // BatchNorm1d eval (models.py:35)
+        }
+        *reinterpret_cast<f32x4 *>(xp) = x;
+    }
+    __syncthreads();
+    for (int it = 0; it < (FB_M * 32) / 512; ++it) {
+        const int idx = it * 512 + tid;
+        const int row = idx >> 5, c = (idx & 31) * 4;
+        const long m = row0 + row;
+        if (m < M) *reinterpret_cast<f32x4 *>(hout + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
+    }
+}
+
 // decision layer (models.py:63,69) for out_dim = 1: y[m] = h[m,:] . w + b ; 32 lanes per row
 __global__ void decision_kernel(const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
                                 float *__restrict__ y, long M) {
@@ -875,9 +1086,23 @@ static hipError_t launch_ffn_mode(const float *part, const float *part_ms, const
     return hipGetLastError();
 }
 
+size_t ffn_packed_bytes() { return kFfnPackedBytes; }
+
+// packed != nullptr (ffn_packed_bytes() of device scratch): the bf16x3 kernel; else the fp32 kernel
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
-                            const float *bn2_s, const float *bn2_b, float *hout, long M, hipStream_t st) {
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, hipStream_t st) {
+    if (packed) {
+        const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 2 * FB_STAGE + 896 * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(ffn_pack_bf16x3_kernel, dim3(64), dim3(256), 0, st, W1, W2, (unsigned char *)packed);
+        hipLaunchKernelGGL(ffn_fused_bf16x3_kernel, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
+                           bn1_s, bn1_b, (const unsigned char *)packed, b1, b2, bn2_s, bn2_b, hout, M);
+        return hipGetLastError();
+    }
     return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,
                                       nullptr, st);
 }
