@@ -758,9 +758,12 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 // so that a stage's 24 KB are a flat copy into LDS and a wavefront's A fragment is one conflict-free ds_read_b128.  The k order of
 // W2p is the accumulator layout of GEMM1 (lane (row, q) holds hidden units 16 ht + 4 q + r of its row): as in the fp32 kernel
 // the hidden layer goes from the accumulators of GEMM1 through ReLU and the split straight into the B operand of GEMM2.
-// One workgroup = 128 rows, 8 wavefronts of 16 rows (two per SIMD), one workgroup per CU (118 KB of LDS: the x tile in fp32 for the
-// skip connection, split on the fly per k block; two 24 KB weight stages).
+// One workgroup = 128 rows, 8 wavefronts of 16 rows (two per SIMD), one workgroup per CU (142 KB of LDS: the x tile in fp32 for the
+// skip connection, split on the fly per k block; a ring of three 24 KB weight stages).
 // ---------------------------------------------------------------------------------------------
+#ifndef FFN_DBG
+#define FFN_DBG 0                    // bits: 1 no main loop, 2 no HBM traffic in the prologue / epilogue, 4 no weight streaming, 8 no MFMAs (time attribution builds)
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FB_M = 128;                          // rows per workgroup
 constexpr int FB_STAGE = 8 * 3 * 64 * 16;          // bytes of one weight stage: 8 tiles x 3 pieces x 64 lanes x 16 B
@@ -815,9 +818,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                                                                   float *__restrict__ hout, long M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
-    unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // two weight stages
-    unsigned char *Wb1 = Wb0 + FB_STAGE;
-    float *vecs = reinterpret_cast<float *>(Wb1 + FB_STAGE);                       // b1[512] b2[128] bn2_s[128] bn2_b[128]
+    unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // ring of three weight stages
+    float *vecs = reinterpret_cast<float *>(Wb0 + 3 * FB_STAGE);                   // b1[512] b2[128] bn2_s[128] bn2_b[128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int wrow = wave * 16;
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
             const long m = row0 + row;
             live[u] = m < M;
-            const long mc = live[u] ? m : 0;
+            const long mc = (FFN_DBG & 2) ? 0 : (live[u] ? m : 0);
             const float *ms0 = part_ms + mc * (2 * kH), *ms1 = part_ms + (M + mc) * (2 * kH);
             m0[u] = ms0[hd]; s0[u] = ms0[kH + hd]; m1[u] = ms1[hd]; s1[u] = ms1[kH + hd];
             p0[u] = *reinterpret_cast<const f32x4 *>(part + mc * kD + c);
@@ -863,7 +865,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         }
     }
 
-    // ---- weight stage stream: stage t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1p, 1: W2p), sub = t&3; a flat 24 KB copy ----
+    // ---- weight stage stream: stage t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1p, 1: W2p), sub = t&3; a flat 24 KB copy.
+    // Ring of THREE stage buffers: stage t computes from buffer t % 3 while the copy of stage t + 2 is in flight (global loads at the
+    // start of the stage, LDS stores at its end), one barrier per stage.  What a wavefront needs to START stage t + 1 -- the pieces
+    // of its B operand and the A fragments of the first tile -- is prepared before that barrier (buffer (t + 1) % 3 has been
+    // complete since the barrier before), so the matrix pipe does not idle through an LDS round trip and a split after every
+    // barrier (measured: 2.5k cycles per stage for 1.5k cycles of MFMAs without this).
     f32x4 rw[3];
     auto gload = [&](int t) {
         const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
@@ -875,55 +882,96 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
 #pragma unroll
         for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4 *>(Wt + tid * 16 + u * 8192) = rw[u];
     };
-    gload(0);
-    lstore(Wb0);
+    unsigned char *const Wb = Wb0;                       // ring base: buffers at Wb + {0, 1, 2} * FB_STAGE
+    gload(0); lstore(Wb);
+    gload(1); lstore(Wb + FB_STAGE);
     __syncthreads();
 
     f32x4 accY[8], accH[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) accY[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto tiles = [&](f32x4 (&acc)[8], const unsigned char *Wt, const bf16x8 &b0, const bf16x8 &b1v, const bf16x8 &b2v) {
+    bf16x8 q0, q1, q2;                                   // B pieces of the current stage
+    bf16x8 fa0, fa1, fa2;                                // A fragments of the current stage's first tile
+    auto x_values = [&](int kb, float (&v)[8]) {         // GEMM1, k block kb: x[row][32 kb + 8 q .. + 7]
+        const float *xp = Xs + (wrow + lr) * LDX + kb * 32 + 8 * lq;
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
 #pragma unroll
-        for (int tl = 0; tl < 8; ++tl) {
-            const unsigned char *f = Wt + (size_t)(tl * 3) * 1024 + lane * 16;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(f);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
-            acc[tl] = mfma_bf16x3(a0, a1, a2, b0, b1v, b2v, acc[tl]);
-        }
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     };
+    auto first_frags = [&](const unsigned char *Wt) {
+        const unsigned char *f = Wt + lane * 16;
+        fa0 = *reinterpret_cast<const bf16x8 *>(f);
+        fa1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
+        fa2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+    };
+    {
+        float v[8];
+        x_values(0, v);
+        split_bf16x3(v, q0, q1, q2);
+    }
+    first_frags(Wb);
+    int rb = 0;                                          // ring slot of the current stage (wave-uniform)
 
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < ((FFN_DBG & 1) ? 0 : 4); ++c) {
         // hidden pre-activations start at the bias (C-in of the MFMA chain), models.py:30
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) accH[ht] = *reinterpret_cast<const f32x4 *>(vecs + c * 128 + ht * 16 + 4 * lq);
 #pragma unroll
         for (int sub = 0; sub < 8; ++sub) {
             const int t = c * 8 + sub;
-            if (t + 1 < 32) gload(t + 1);
-            const unsigned char *Wt = (sub & 1) ? Wb1 : Wb0;
+            const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
+            if (t + 2 < 32 && !(FFN_DBG & 4)) gload(t + 2);
+            const unsigned char *Wt = Wb + rb * FB_STAGE;
+            // the B operand of the NEXT stage, prepared in four slices under this stage's MFMAs: x values of the next k block (sub 0..2, and
+            // 7: the next chunk's first), or ReLU(hidden) of block j = sub - 3, whose two tiles are complete once this stage's tiles 0 and 1
+            // are (sub 3) or have been since the last GEMM1 stage (sub 4..6), models.py:31
             float v[8];
-            if (sub < 4) {                               // GEMM1, k block `sub`: B = the pieces of x[row][32 sub + 8 q .. + 7]
-                const float *xp = Xs + (wrow + lr) * LDX + sub * 32 + 8 * lq;
-                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-            } else {                                     // GEMM2, hidden block j = sub - 4: B = the pieces of ReLU(hidden), models.py:31
-                const int j = sub - 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u0 = accH[2 * j][e], u1 = accH[2 * j + 1][e];
-                    v[e] = u0 > 0.f ? u0 : 0.f; v[4 + e] = u1 > 0.f ? u1 : 0.f;
+            if (sub < 3) x_values(sub + 1, v);
+            else if (sub == 7) x_values(0, v);
+            bf16x8 n0, n1, n2;
+            auto slice = [&](int k) {                    // elements 2 k, 2 k + 1
+                if (sub >= 3 && sub < 7) {
+                    const int j = sub - 3, hh = k >> 1, e0 = 2 * (k & 1);
+                    const float u0 = accH[2 * j + hh][e0], u1 = accH[2 * j + hh][e0 + 1];
+                    v[2 * k] = u0 > 0.f ? u0 : 0.f; v[2 * k + 1] = u1 > 0.f ? u1 : 0.f;
                 }
+#pragma unroll
+                for (int e = 2 * k; e < 2 * k + 2; ++e) {
+                    const __bf16 h0 = (__bf16)v[e];
+                    const float r1 = v[e] - (float)h0;
+                    const __bf16 h1 = (__bf16)r1;
+                    const float r2 = r1 - (float)h1;
+                    n0[e] = h0; n1[e] = h1; n2[e] = (__bf16)r2;
+                }
+            };
+            // issue order of the stage, fixed by hand (nothing crosses a sched_barrier): the fragments of tile tl + 1, the six MFMAs of tile
+            // tl, a slice of the split in the issue slots the MFMAs leave free (an MFMA of 16 cycles holds the issue port for 8)
+            bf16x8 a0 = fa0, a1 = fa1, a2 = fa2;
+#pragma unroll
+            for (int tl = 0; tl < 8; ++tl) {
+                bf16x8 m0 = a0, m1 = a1, m2 = a2;
+                if (tl < 7) {
+                    const unsigned char *f = Wt + (size_t)((tl + 1) * 3) * 1024 + lane * 16;
+                    m0 = *reinterpret_cast<const bf16x8 *>(f);
+                    m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
+                    m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(FFN_DBG & 8)) {
+                    if (sub < 4) accH[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, accH[tl]);
+                    else accY[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, accY[tl]);
+                }
+                if (tl >= 3 && tl < 7) slice(tl - 3);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = m0; a1 = m1; a2 = m2;
             }
-            bf16x8 q0, q1, q2;
-            split_bf16x3(v, q0, q1, q2);
-            if (sub < 4) tiles(accH, Wt, q0, q1, q2);
-            else tiles(accY, Wt, q0, q1, q2);
-            if (t + 1 < 32) lstore((sub & 1) ? Wb0 : Wb1);
+            q0 = n0; q1 = n1; q2 = n2;
+            if (t + 2 < 32 && !(FFN_DBG & 4)) lstore(Wb + rb2 * FB_STAGE);
+            first_frags(Wb + rb1 * FB_STAGE);
             __syncthreads();
+            rb = rb1;
         }
     }
 
@@ -949,7 +997,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         const int idx = it * 512 + tid;
         const int row = idx >> 5, c = (idx & 31) * 4;
         const long m = row0 + row;
-        if (m < M) *reinterpret_cast<f32x4 *>(hout + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
+        if (m < M && (!(FFN_DBG & 2) || m == 0)) *reinterpret_cast<f32x4 *>(hout + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
     }
 }
 
@@ -1093,7 +1141,7 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, hipStream_t st) {
     if (packed) {
-        const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 2 * FB_STAGE + 896 * sizeof(float);
+        const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -10,7 +10,7 @@ run() {   # name, counters...
   name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/tmp_$name -o $name -- python3 scripts/probe_forward.py 100 512 2 > $out/$name.log 2>&1
   f=$(find $out/tmp_$name -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then grep -E "Counter_Name|ffn_fused_kernel|gat_rows_kernel|gemm_f32_kernel" "$f" > $out/${name}_counter_collection.csv; fi
+  if [ -n "$f" ]; then grep -E "Counter_Name|ffn_fused|gat_rows_kernel|gemm_f32_kernel" "$f" > $out/${name}_counter_collection.csv; fi
   rm -rf $out/tmp_$name
   tail -2 $out/$name.log
 }

@@ -18,7 +18,7 @@ def read(path):
     launches = defaultdict(int)
     with open(path) as f:
         for r in csv.DictReader(f):
-            k = next(n for n in ("ffn_fused_kernel", "gat_rows_kernel", "gemm_f32_kernel") if n in r["Kernel_Name"])
+            k = next(n for n in ("ffn_fused_bf16x3_kernel", "ffn_pack_bf16x3_kernel", "ffn_fused_kernel", "gat_rows_kernel", "gemm_f32_kernel") if n in r["Kernel_Name"])
             rows[k][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"):
                 span[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
@@ -60,7 +60,7 @@ def main():
         rnd = os.path.basename(os.path.normpath(d)).split("_")[0][:3]
         path = os.path.join(root, "profiles", f"traffic_{rnd}.json")
         table = json.load(open(path)) if os.path.isfile(path) else {}
-        for name, kern in (("ffn_fused", "ffn_fused_kernel"), ("gemm_fc", "gemm_f32_kernel"), ("gat_aggregate", "gat_rows_kernel")):
+        for name, kern in (("ffn_fused", "ffn_fused_kernel"), ("ffn_fused", "ffn_fused_bf16x3_kernel"), ("gemm_fc", "gemm_f32_kernel"), ("gat_aggregate", "gat_rows_kernel")):
             if kern in out:
                 table[name] = dict(out[kern], source=f"{rel}/*_counter_collection.csv (scripts/pmc_forward.sh: predict_regret, 512 TSP100 instances)")
         json.dump(table, open(path, "w"), indent=1)
