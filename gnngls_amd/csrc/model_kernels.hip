@@ -866,25 +866,26 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
     }
 
     // ---- weight stage stream: stage t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1p, 1: W2p), sub = t&3; a flat 24 KB copy.
-    // Ring of THREE stage buffers: stage t computes from buffer t % 3 while the copy of stage t + 2 is in flight (global loads at the
-    // start of the stage, LDS stores at its end), one barrier per stage.  What a wavefront needs to START stage t + 1 -- the pieces
+    // Ring of THREE stage buffers: stage t computes from buffer t % 3 while the copies of stages t + 2 and t + 3 are in flight (global loads
+    // at the start of stage t - 1 / t, LDS stores at the end of stage t / t + 1), one barrier per stage.  What a wavefront needs to START stage t + 1 -- the pieces
     // of its B operand and the A fragments of the first tile -- is prepared before that barrier (buffer (t + 1) % 3 has been
     // complete since the barrier before), so the matrix pipe does not idle through an LDS round trip and a split after every
     // barrier (measured: 2.5k cycles per stage for 1.5k cycles of MFMAs without this).
-    f32x4 rw[3];
-    auto gload = [&](int t) {
+    f32x4 rwA[3], rwB[3];                                // two copies in flight: loaded three stages ahead, stored two stages ahead
+    auto gload = [&](int t, f32x4 (&rw)[3]) {
         const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
         const unsigned char *src = packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE + tid * 16;
 #pragma unroll
         for (int u = 0; u < 3; ++u) rw[u] = *reinterpret_cast<const f32x4 *>(src + u * 8192);
     };
-    auto lstore = [&](unsigned char *Wt) {
+    auto lstore = [&](unsigned char *Wt, const f32x4 (&rw)[3]) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4 *>(Wt + tid * 16 + u * 8192) = rw[u];
     };
     unsigned char *const Wb = Wb0;                       // ring base: buffers at Wb + {0, 1, 2} * FB_STAGE
-    gload(0); lstore(Wb);
-    gload(1); lstore(Wb + FB_STAGE);
+    gload(0, rwA); lstore(Wb, rwA);
+    gload(1, rwA); lstore(Wb + FB_STAGE, rwA);
+    gload(2, rwB);
     __syncthreads();
 
     f32x4 accY[8], accH[8];
@@ -899,11 +900,16 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
     };
+    bf16x8 fb0, fb1, fb2;                                // ... and of its second tile (fragments are read two tiles ahead: one tile's
+                                                         // six MFMAs, 96 cycles, do not cover an LDS round trip with eight wavefronts reading)
     auto first_frags = [&](const unsigned char *Wt) {
         const unsigned char *f = Wt + lane * 16;
         fa0 = *reinterpret_cast<const bf16x8 *>(f);
         fa1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
         fa2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+        fb0 = *reinterpret_cast<const bf16x8 *>(f + 3072);
+        fb1 = *reinterpret_cast<const bf16x8 *>(f + 4096);
+        fb2 = *reinterpret_cast<const bf16x8 *>(f + 5120);
     };
     {
         float v[8];
@@ -922,7 +928,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         for (int sub = 0; sub < 8; ++sub) {
             const int t = c * 8 + sub;
             const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
-            if (t + 2 < 32 && !(FFN_DBG & 4)) gload(t + 2);
+            if (t + 3 < 32 && !(FFN_DBG & 4)) { if (sub & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
+            __builtin_amdgcn_sched_barrier(0);           // the copy's global loads stay at the start of the stage
             const unsigned char *Wt = Wb + rb * FB_STAGE;
             // the B operand of the NEXT stage, prepared in four slices under this stage's MFMAs: x values of the next k block (sub 0..2, and
             // 7: the next chunk's first), or ReLU(hidden) of block j = sub - 3, whose two tiles are complete once this stage's tiles 0 and 1
@@ -948,12 +955,13 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             };
             // issue order of the stage, fixed by hand (nothing crosses a sched_barrier): the fragments of tile tl + 1, the six MFMAs of tile
             // tl, a slice of the split in the issue slots the MFMAs leave free (an MFMA of 16 cycles holds the issue port for 8)
-            bf16x8 a0 = fa0, a1 = fa1, a2 = fa2;
+            bf16x8 a0 = fa0, a1 = fa1, a2 = fa2, b0 = fb0, b1 = fb1, b2 = fb2;
 #pragma unroll
             for (int tl = 0; tl < 8; ++tl) {
-                bf16x8 m0 = a0, m1 = a1, m2 = a2;
-                if (tl < 7) {
-                    const unsigned char *f = Wt + (size_t)((tl + 1) * 3) * 1024 + lane * 16;
+                bf16x8 m0 = b0, m1 = b1, m2 = b2;
+                {   // tiles 2 .. 7 of this stage, then tiles 0 and 1 of the NEXT stage's buffer (complete since the last barrier): the wave
+                    // reaches the barrier with the next stage's first operands already in registers
+                    const unsigned char *f = (tl < 6 ? Wt + (size_t)((tl + 2) * 3) * 1024 : Wb + rb1 * FB_STAGE + (size_t)((tl - 6) * 3) * 1024) + lane * 16;
                     m0 = *reinterpret_cast<const bf16x8 *>(f);
                     m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
                     m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
@@ -965,11 +973,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                 }
                 if (tl >= 3 && tl < 7) slice(tl - 3);
                 __builtin_amdgcn_sched_barrier(0);
-                a0 = m0; a1 = m1; a2 = m2;
+                a0 = b0; a1 = b1; a2 = b2;
+                b0 = m0; b1 = m1; b2 = m2;
             }
             q0 = n0; q1 = n1; q2 = n2;
-            if (t + 2 < 32 && !(FFN_DBG & 4)) lstore(Wb + rb2 * FB_STAGE);
-            first_frags(Wb + rb1 * FB_STAGE);
+            fa0 = a0; fa1 = a1; fa2 = a2; fb0 = b0; fb1 = b1; fb2 = b2;
+            if (t + 2 < 32 && !(FFN_DBG & 4)) { if (sub & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
             __syncthreads();
             rb = rb1;
         }
