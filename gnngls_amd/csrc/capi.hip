@@ -443,13 +443,17 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
             const float *bn1_s = attn_r + 128, *bn1_b = bn1_s + 128;
             const float *w1 = bn1_b + 128, *b1 = w1 + 512L * 128, *w2 = b1 + 512, *b2 = w2 + 128L * 512;
             const float *bn2_s = b2 + 128, *bn2_b = bn2_s + 128;
-            { ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
+            // ft = fc(h), models.py:23: a launch of its own for the first layer (and for every layer on the fp32 path); on the bf16x3 path
+            // the feed-forward launch of layer l - 1 has already written it (fc folded into that kernel's tail)
+            if (l == 0 || !ffn_ws.p) {
+              ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
-            // gat_combine + FFN1 + FFN2 in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
+            // gat_combine + FFN1 + FFN2 (+ the next layer's fc) in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
-              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, ffn_ws.p, st)); }
+              const float *fc_next = (ffn_ws.p && l + 1 < n_layers) ? layers + (long)(l + 1) * kLayerFloats : nullptr;
+              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, ffn_ws.p, fc_next, ft, st)); }
             { float *x = h; h = h2; h2 = x; }
         }
         { ProfScope ps(GNNGLS_PROF_DECISION, st);

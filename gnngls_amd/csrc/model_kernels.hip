@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FB_M = 128;                          // rows per workgroup
 constexpr int FB_STAGE = 8 * 3 * 64 * 16;          // bytes of one weight stage: 8 tiles x 3 pieces x 64 lanes x 16 B
-constexpr size_t kFfnPackedBytes = (size_t)2 * 16 * FB_STAGE;      // W1p + W2p: 786,432 B
+constexpr size_t kFfnPackedBytes = (size_t)(2 * 16 + 4) * FB_STAGE;  // W1p + W2p + the next layer's fc: 884,736 B
 
 __device__ __forceinline__ void split_bf16x3(const float (&x)[8], bf16x8 &p0, bf16x8 &p1, bf16x8 &p2) {
 #pragma unroll
@@ -809,13 +809,30 @@ __global__ void ffn_pack_bf16x3_kernel(const float *__restrict__ W1, const float
     *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
 }
 
+// the next layer's fc weights [128 f][128 k] in the W2p form: Wfp[j][tile][p][lane][8] = piece p of Wfc[16 tile + (lane & 15)][32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
+__global__ void ffn_pack_fc_bf16x3_kernel(const float *__restrict__ Wfc, unsigned char *__restrict__ packed_fc) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;             // 4 x 8 x 64 = 2048 threads
+    const int lane = g & 63, tile = (g >> 6) & 7, j = g >> 9;
+    const int lr = lane & 15, lq = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = Wfc[(long)(tile * 16 + lr) * 128 + 32 * j + 16 * (e >> 2) + 4 * lq + (e & 3)];
+    bf16x8 p0, p1, p2;
+    split_bf16x3(v, p0, p1, p2);
+    unsigned char *dst = packed_fc + (size_t)j * FB_STAGE + (size_t)(tile * 3) * 1024 + lane * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = p0;
+    *reinterpret_cast<bf16x8 *>(dst + 1024) = p1;
+    *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
+}
+
 __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
                                                                   const float *__restrict__ hin,
                                                                   const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
                                                                   const unsigned char *__restrict__ packed, const float *__restrict__ b1,
                                                                   const float *__restrict__ b2,
                                                                   const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
-                                                                  float *__restrict__ hout, long M) {
+                                                                  float *__restrict__ hout, long M,
+                                                                  const unsigned char *__restrict__ packed_fc, float *__restrict__ ft_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
     unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // ring of three weight stages
@@ -872,9 +889,11 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
     // complete since the barrier before), so the matrix pipe does not idle through an LDS round trip and a split after every
     // barrier (measured: 2.5k cycles per stage for 1.5k cycles of MFMAs without this).
     f32x4 rwA[3], rwB[3];                                // two copies in flight: loaded three stages ahead, stored two stages ahead
+    const int nst = packed_fc ? 36 : 32;                 // stages 32 .. 35: the NEXT layer's fc (GATConv's linear map, models.py:23) on this layer's output
     auto gload = [&](int t, f32x4 (&rw)[3]) {
         const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
-        const unsigned char *src = packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE + tid * 16;
+        const unsigned char *src = (t < 32 ? packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE
+                                           : packed_fc + (size_t)(t - 32) * FB_STAGE) + tid * 16;
 #pragma unroll
         for (int u = 0; u < 3; ++u) rw[u] = *reinterpret_cast<const f32x4 *>(src + u * 8192);
     };
@@ -911,6 +930,38 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         fb1 = *reinterpret_cast<const bf16x8 *>(f + 4096);
         fb2 = *reinterpret_cast<const bf16x8 *>(f + 5120);
     };
+    // One stage's MFMAs with the issue order fixed by hand (nothing crosses a sched_barrier): the fragments two tiles ahead -- tiles 2 .. 7 of
+    // this stage, then tiles 0 and 1 of the NEXT stage's buffer (complete since the last barrier), so that the wave reaches the barrier with
+    // the next stage's first operands in registers --, the six MFMAs of tile tl, and a slice of the next stage's split in the issue slots the
+    // MFMAs leave free (an MFMA of 16 cycles holds the issue port for 8)
+    auto run_tiles = [&](f32x4 (&acc)[8], const unsigned char *Wt, const unsigned char *Wnext, auto &&slice) {
+        bf16x8 a0 = fa0, a1 = fa1, a2 = fa2, b0 = fb0, b1 = fb1, b2 = fb2;
+#pragma unroll
+        for (int tl = 0; tl < 8; ++tl) {
+            const unsigned char *f = (tl < 6 ? Wt + (size_t)((tl + 2) * 3) * 1024 : Wnext + (size_t)((tl - 6) * 3) * 1024) + lane * 16;
+            const bf16x8 m0 = *reinterpret_cast<const bf16x8 *>(f);
+            const bf16x8 m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
+            const bf16x8 m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(FFN_DBG & 8)) acc[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, acc[tl]);
+            if (tl >= 3 && tl < 7) slice(tl - 3);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = b0; a1 = b1; a2 = b2;
+            b0 = m0; b1 = m1; b2 = m2;
+        }
+        fa0 = a0; fa1 = a1; fa2 = a2; fb0 = b0; fb1 = b1; fb2 = b2;
+    };
+    // elements 2 k, 2 k + 1 of a B operand: the three bf16 pieces of v[.]
+    auto split_pair = [&](const float (&v)[8], int k, bf16x8 &n0, bf16x8 &n1, bf16x8 &n2) {
+#pragma unroll
+        for (int e = 2 * k; e < 2 * k + 2; ++e) {
+            const __bf16 h0 = (__bf16)v[e];
+            const float r1 = v[e] - (float)h0;
+            const __bf16 h1 = (__bf16)r1;
+            const float r2 = r1 - (float)h1;
+            n0[e] = h0; n1[e] = h1; n2[e] = (__bf16)r2;
+        }
+    };
     {
         float v[8];
         x_values(0, v);
@@ -928,7 +979,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         for (int sub = 0; sub < 8; ++sub) {
             const int t = c * 8 + sub;
             const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
-            if (t + 3 < 32 && !(FFN_DBG & 4)) { if (sub & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
+            if (t + 3 < nst && !(FFN_DBG & 4)) { if (sub & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
             __builtin_amdgcn_sched_barrier(0);           // the copy's global loads stay at the start of the stage
             const unsigned char *Wt = Wb + rb * FB_STAGE;
             // the B operand of the NEXT stage, prepared in four slices under this stage's MFMAs: x values of the next k block (sub 0..2, and
@@ -944,41 +995,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                     const float u0 = accH[2 * j + hh][e0], u1 = accH[2 * j + hh][e0 + 1];
                     v[2 * k] = u0 > 0.f ? u0 : 0.f; v[2 * k + 1] = u1 > 0.f ? u1 : 0.f;
                 }
-#pragma unroll
-                for (int e = 2 * k; e < 2 * k + 2; ++e) {
-                    const __bf16 h0 = (__bf16)v[e];
-                    const float r1 = v[e] - (float)h0;
-                    const __bf16 h1 = (__bf16)r1;
-                    const float r2 = r1 - (float)h1;
-                    n0[e] = h0; n1[e] = h1; n2[e] = (__bf16)r2;
-                }
+                split_pair(v, k, n0, n1, n2);
             };
-            // issue order of the stage, fixed by hand (nothing crosses a sched_barrier): the fragments of tile tl + 1, the six MFMAs of tile
-            // tl, a slice of the split in the issue slots the MFMAs leave free (an MFMA of 16 cycles holds the issue port for 8)
-            bf16x8 a0 = fa0, a1 = fa1, a2 = fa2, b0 = fb0, b1 = fb1, b2 = fb2;
-#pragma unroll
-            for (int tl = 0; tl < 8; ++tl) {
-                bf16x8 m0 = b0, m1 = b1, m2 = b2;
-                {   // tiles 2 .. 7 of this stage, then tiles 0 and 1 of the NEXT stage's buffer (complete since the last barrier): the wave
-                    // reaches the barrier with the next stage's first operands already in registers
-                    const unsigned char *f = (tl < 6 ? Wt + (size_t)((tl + 2) * 3) * 1024 : Wb + rb1 * FB_STAGE + (size_t)((tl - 6) * 3) * 1024) + lane * 16;
-                    m0 = *reinterpret_cast<const bf16x8 *>(f);
-                    m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
-                    m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(FFN_DBG & 8)) {
-                    if (sub < 4) accH[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, accH[tl]);
-                    else accY[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, accY[tl]);
-                }
-                if (tl >= 3 && tl < 7) slice(tl - 3);
-                __builtin_amdgcn_sched_barrier(0);
-                a0 = b0; a1 = b1; a2 = b2;
-                b0 = m0; b1 = m1; b2 = m2;
-            }
+            if (sub < 4) run_tiles(accH, Wt, Wb + rb1 * FB_STAGE, slice);
+            else run_tiles(accY, Wt, Wb + rb1 * FB_STAGE, slice);
             q0 = n0; q1 = n1; q2 = n2;
-            fa0 = a0; fa1 = a1; fa2 = a2; fb0 = b0; fb1 = b1; fb2 = b2;
-            if (t + 2 < 32 && !(FFN_DBG & 4)) { if (sub & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
+            if (t + 2 < nst && !(FFN_DBG & 4)) { if (sub & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
             __syncthreads();
             rb = rb1;
         }
@@ -1000,13 +1022,57 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             x[r] = v * sc[r] + sh[r];                 // BatchNorm1d eval (models.py:35)
         }
         *reinterpret_cast<f32x4 *>(xp) = x;
+        accH[ot] = x;                                 // (the layer's output in the accumulator layout: the B operand of the fc stages)
     }
-    __syncthreads();
-    for (int it = 0; it < (FB_M * 32) / 512; ++it) {
-        const int idx = it * 512 + tid;
-        const int row = idx >> 5, c = (idx & 31) * 4;
-        const long m = row0 + row;
-        if (m < M && (!(FFN_DBG & 2) || m == 0)) *reinterpret_cast<f32x4 *>(hout + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
+    auto store_tile = [&](float *dst) {               // the tile in Xs, coalesced rows
+        for (int it = 0; it < (FB_M * 32) / 512; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx >> 5, c = (idx & 31) * 4;
+            const long m = row0 + row;
+            if (m < M && (!(FFN_DBG & 2) || m == 0)) *reinterpret_cast<f32x4 *>(dst + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
+        }
+    };
+    if (packed_fc) {
+        // ---- the next layer's ft = fc(h) chained from the registers exactly as GEMM2 is chained from GEMM1: lane (row, q) holds outputs
+        // 16 ot + 4 q + r of its row, which is the k order the packed fc weights are laid out in (ffn_pack_fc_bf16x3_kernel) ----
+#pragma unroll
+        for (int a = 0; a < 8; ++a) accY[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = accH[0][e]; v[4 + e] = accH[1][e]; }
+            split_bf16x3(v, q0, q1, q2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 32 + j;
+            const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
+            if (t + 3 < nst && !(FFN_DBG & 4)) { if (j & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
+            __builtin_amdgcn_sched_barrier(0);
+            float v[8];
+            bf16x8 n0 = q0, n1 = q1, n2 = q2;
+            auto slice = [&](int k) {
+                if (j < 3) {
+                    const int hh = k >> 1, e0 = 2 * (k & 1);
+                    v[2 * k] = accH[2 * (j + 1) + hh][e0]; v[2 * k + 1] = accH[2 * (j + 1) + hh][e0 + 1];
+                    split_pair(v, k, n0, n1, n2);
+                }
+            };
+            run_tiles(accY, Wb + rb * FB_STAGE, Wb + rb1 * FB_STAGE, slice);
+            q0 = n0; q1 = n1; q2 = n2;
+            if (t + 2 < nst && !(FFN_DBG & 4)) { if (j & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
+            __syncthreads();
+            rb = rb1;
+        }
+        store_tile(hout);                             // (the barriers of the fc stages lie between the tile's writes and these reads)
+        __syncthreads();
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) *reinterpret_cast<f32x4 *>(Xs + (wrow + lr) * LDX + ot * 16 + 4 * lq) = accY[ot];
+        __syncthreads();
+        store_tile(ft_out);
+    } else {
+        __syncthreads();
+        store_tile(hout);
     }
 }
 
@@ -1145,19 +1211,24 @@ static hipError_t launch_ffn_mode(const float *part, const float *part_ms, const
 
 size_t ffn_packed_bytes() { return kFfnPackedBytes; }
 
-// packed != nullptr (ffn_packed_bytes() of device scratch): the bf16x3 kernel; else the fp32 kernel
+// packed != nullptr (ffn_packed_bytes() of device scratch): the bf16x3 kernel; else the fp32 kernel.  With the bf16x3 kernel and
+// fc_next != nullptr the NEXT layer's ft = fc_next(hout) [M,128] is written to ft_out by the same launch (models.py:23 of layer l + 1)
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
-                            const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, hipStream_t st) {
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, const float *fc_next,
+                            float *ft_out, hipStream_t st) {
     if (packed) {
         const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(ffn_pack_bf16x3_kernel, dim3(64), dim3(256), 0, st, W1, W2, (unsigned char *)packed);
+        unsigned char *pk = (unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
+        hipLaunchKernelGGL(ffn_pack_bf16x3_kernel, dim3(64), dim3(256), 0, st, W1, W2, pk);
+        if (fc_next) hipLaunchKernelGGL(ffn_pack_fc_bf16x3_kernel, dim3(8), dim3(256), 0, st, fc_next, pk_fc);
         hipLaunchKernelGGL(ffn_fused_bf16x3_kernel, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
-                           bn1_s, bn1_b, (const unsigned char *)packed, b1, b2, bn2_s, bn2_b, hout, M);
+                           bn1_s, bn1_b, (const unsigned char *)pk, b1, b2, bn2_s, bn2_b, hout, M,
+                           (const unsigned char *)(fc_next ? pk_fc : nullptr), ft_out);
         return hipGetLastError();
     }
     return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,
