@@ -883,28 +883,29 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
     }
 
     // ---- weight stage stream: stage t in [0,32): chunk c = t>>3, phase (t>>2)&1 (0: W1p, 1: W2p), sub = t&3; a flat 24 KB copy.
-    // Ring of THREE stage buffers: stage t computes from buffer t % 3 while the copies of stages t + 2 and t + 3 are in flight (global loads
-    // at the start of stage t - 1 / t, LDS stores at the end of stage t / t + 1), one barrier per stage.  What a wavefront needs to START stage t + 1 -- the pieces
+    // Ring of THREE stage buffers: stage t computes from buffer t % 3 while the copy of stage t + 2 is in flight (issued at the start of
+    // stage t, waited for at its end), one barrier per stage.  What a wavefront needs to START stage t + 1 -- the pieces
     // of its B operand and the A fragments of the first tile -- is prepared before that barrier (buffer (t + 1) % 3 has been
     // complete since the barrier before), so the matrix pipe does not idle through an LDS round trip and a split after every
     // barrier (measured: 2.5k cycles per stage for 1.5k cycles of MFMAs without this).
-    f32x4 rwA[3], rwB[3];                                // two copies in flight: loaded three stages ahead, stored two stages ahead
     const int nst = packed_fc ? 36 : 32;                 // stages 32 .. 35: the NEXT layer's fc (GATConv's linear map, models.py:23) on this layer's output
-    auto gload = [&](int t, f32x4 (&rw)[3]) {
+    // LDS-DMA (global_load_lds_dwordx4: every wavefront instruction moves 1 KB, lane l's 16 bytes to LDS base + 16 l): no staging
+    // registers, no ds_write, the copy is tracked by vmcnt alone
+    auto dma_stage = [&](int t, unsigned char *Wt) {
         const int c = t >> 3, ph = (t >> 2) & 1, sub = t & 3;
-        const unsigned char *src = (t < 32 ? packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE
-                                           : packed_fc + (size_t)(t - 32) * FB_STAGE) + tid * 16;
+        const unsigned char *src = t < 32 ? packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE
+                                          : packed_fc + (size_t)(t - 32) * FB_STAGE;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) rw[u] = *reinterpret_cast<const f32x4 *>(src + u * 8192);
-    };
-    auto lstore = [&](unsigned char *Wt, const f32x4 (&rw)[3]) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) *reinterpret_cast<f32x4 *>(Wt + tid * 16 + u * 8192) = rw[u];
+        for (int u = 0; u < 3; ++u) {
+            const int piece = (u * 8 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece + lane * 16),
+                                             (__attribute__((address_space(3))) void *)(Wt + piece), 16, 0, 0);
+        }
     };
     unsigned char *const Wb = Wb0;                       // ring base: buffers at Wb + {0, 1, 2} * FB_STAGE
-    gload(0, rwA); lstore(Wb, rwA);
-    gload(1, rwA); lstore(Wb + FB_STAGE, rwA);
-    gload(2, rwB);
+    dma_stage(0, Wb);
+    dma_stage(1, Wb + FB_STAGE);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the copies have landed
     __syncthreads();
 
     f32x4 accY[8], accH[8];
@@ -979,8 +980,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         for (int sub = 0; sub < 8; ++sub) {
             const int t = c * 8 + sub;
             const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
-            if (t + 3 < nst && !(FFN_DBG & 4)) { if (sub & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
-            __builtin_amdgcn_sched_barrier(0);           // the copy's global loads stay at the start of the stage
+            if (t + 2 < nst && !(FFN_DBG & 4)) dma_stage(t + 2, Wb + rb2 * FB_STAGE);      // (buffer rb2 was last read in stage t - 1)
+            __builtin_amdgcn_sched_barrier(0);           // the copy is issued at the start of the stage
             const unsigned char *Wt = Wb + rb * FB_STAGE;
             // the B operand of the NEXT stage, prepared in four slices under this stage's MFMAs: x values of the next k block (sub 0..2, and
             // 7: the next chunk's first), or ReLU(hidden) of block j = sub - 3, whose two tiles are complete once this stage's tiles 0 and 1
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             if (sub < 4) run_tiles(accH, Wt, Wb + rb1 * FB_STAGE, slice);
             else run_tiles(accY, Wt, Wb + rb1 * FB_STAGE, slice);
             q0 = n0; q1 = n1; q2 = n2;
-            if (t + 2 < nst && !(FFN_DBG & 4)) { if (sub & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
+            __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): this wavefront's share of stage t + 2 has landed
             __syncthreads();
             rb = rb1;
         }
@@ -1047,7 +1048,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         for (int j = 0; j < 4; ++j) {
             const int t = 32 + j;
             const int rb1 = rb == 2 ? 0 : rb + 1, rb2 = rb1 == 2 ? 0 : rb1 + 1;
-            if (t + 3 < nst && !(FFN_DBG & 4)) { if (j & 1) gload(t + 3, rwB); else gload(t + 3, rwA); }
+            if (t + 2 < nst && !(FFN_DBG & 4)) dma_stage(t + 2, Wb + rb2 * FB_STAGE);
             __builtin_amdgcn_sched_barrier(0);
             float v[8];
             bf16x8 n0 = q0, n1 = q1, n2 = q2;
@@ -1060,7 +1061,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             };
             run_tiles(accY, Wb + rb * FB_STAGE, Wb + rb1 * FB_STAGE, slice);
             q0 = n0; q1 = n1; q2 = n2;
-            if (t + 2 < nst && !(FFN_DBG & 4)) { if (j & 1) lstore(Wb + rb2 * FB_STAGE, rwA); else lstore(Wb + rb2 * FB_STAGE, rwB); }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
             rb = rb1;
         }
