@@ -256,7 +256,7 @@ __device__ __forceinline__ void block_reduce_best_lds(Ctl *ctl, int &phase, int 
 // s_and_saveexec, s_cbranch_execz, s_or: four instructions and ~45 cycles of the wavefront, entered or not) per group instead of
 // one per step, for U - 1 v_min_f64.  Same-box A/B (profiles/r05_experiments/ab_descent_*.log, outer iterations per 2 s, TSP100 x
 // 1024, model guide): 22.40k -> 23.13k; with six steps per group in the relocate scan (GLS_LEAN_UNROLL_RELOCATE) 23.48k, TSP50 x 128
-// 27.80k -> 28.04k (six steps in the 2-opt scan too: 27.47k; eight: 26.2k).
+// 27.80k -> 28.04k (six steps in the 2-opt scan too: 27.47k; eight: 26.2k).  Per build: MF / UR template arguments of the scans.
 #ifndef GLS_LEAN_MINFILTER
 #define GLS_LEAN_MINFILTER 1
 #endif
@@ -270,9 +270,9 @@ __device__ __forceinline__ double min_tree(const double (&dl)[U]) {
     if constexpr (HI - LO == 1) return dl[LO];
     else return min_f64_raw(min_tree<LO, (LO + HI) / 2>(dl), min_tree<(LO + HI) / 2, HI>(dl));
 }
-template <int U>
+template <bool MF, int U>
 __device__ __forceinline__ bool group_may_improve(const double (&dl)[U], double bd) {
-    if constexpr (!GLS_LEAN_MINFILTER || U == 1) return true;
+    if constexpr (!MF || !GLS_LEAN_MINFILTER || U == 1) return true;
     else return min_tree<0, U>(dl) < bd;
 }
 template <int SL>
@@ -348,7 +348,9 @@ __device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, 
 // lanes the half of the lanes with b < e reads 64 consecutive doubles of row e and the other half a fixed quadratic
 // pattern (b(b-1)/2 + e), instead of 64 arbitrary rows / columns: simulated 2.5 instead of 4.9 bank passes per
 // ds_read_b64 at n = 100.  Keys (i, j) and deltas are the same set; within a lane they still ascend with k.
-template <int SL, class S, class TT>
+// MF: the group filter above; UR: steps per group -- both chosen by the caller from the register budget of the build (the filter costs
+// 16-28 B of scratch on the 64- / 80-VGPR builds, six steps per group 8-20 B on the single-slot 128-VGPR ones: those keep round 4's code)
+template <int SL, bool MF, int UR, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, const double *Ef, int n,
                                                        int wave, int nwaves, int lane, double &bd, int &bk,
                                                        const uint8_t *pos = nullptr) {
@@ -397,7 +399,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             dl[u] = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
         }
-        if (!group_may_improve(dl, bd)) return;              // one exec-masked region per group instead of one per step
+        if (!group_may_improve<MF>(dl, bd)) return;          // one exec-masked region per group instead of one per step
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = k + u;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             }
         }
     };
-    using UN = std::integral_constant<int, GLS_LEAN_UNROLL_RELOCATE>;
+    using UN = std::integral_constant<int, UR>;
     using U1 = std::integral_constant<int, 1>;
     using FAST = std::integral_constant<bool, true>;
     using EXACT = std::integral_constant<bool, false>;
@@ -419,7 +421,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
         const int lo = q * kWave - 1, hi = q * kWave + kWave - 1;
         int k = k0 > lo ? k0 : lo;
         const int ke = k1f < hi ? k1f : hi;
-        for (; k + GLS_LEAN_UNROLL_RELOCATE <= ke; k += GLS_LEAN_UNROLL_RELOCATE) group(k, L.t[q], UN{}, FAST{});
+        for (; k + UR <= ke; k += UR) group(k, L.t[q], UN{}, FAST{});
         for (; k < ke; ++k) group(k, L.t[q], U1{}, FAST{});
     }
     if (k1f != k1) {                                         // keys ascend with k within a lane: the last step stays last
@@ -429,7 +431,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     }
 }
 
-template <int SL, class S, class TT>
+template <int SL, bool MF, class S, class TT>
 __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, const double *Eb, int n,
                                                       int wave, int nwaves, int lane, double &bd, int &bk) {
     // combinations(range(1,n),2), |i-j| >= 2 (operators.py:36-39): rows i = 1..n-3, j = i+2..n-1.  Row block rb can use
@@ -475,7 +477,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_lean(const S &s, const TT *t, c
             delta = delta - eab;
             dl[u] = delta - ecd[u];
         }
-        if (!group_may_improve(dl, bd)) return;
+        if (!group_may_improve<MF>(dl, bd)) return;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const double delta = dl[u];

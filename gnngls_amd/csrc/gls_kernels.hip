@@ -183,8 +183,11 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                     lean = true;
                 }
                 if (!lean && nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
-                    if (op == 0) scan_two_opt_a2a_lean<GP, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
-                    else         scan_relocate_a2a_lean<GP, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
+                    // group filter on the 128-VGPR and wider builds, six steps per relocate group where two register slots leave room
+                    constexpr bool kMF = WPS <= 4;
+                    constexpr int kUR = (WPS <= 4 && GP == 2) ? GLS_LEAN_UNROLL_RELOCATE : GLS_LEAN_UNROLL;
+                    if (op == 0) scan_two_opt_a2a_lean<GP, kMF, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                    else         scan_relocate_a2a_lean<GP, kMF, kUR, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
                     lean = true;
                 }
             }
