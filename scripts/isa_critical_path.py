@@ -99,7 +99,7 @@ def main():
         "instantiation": "gls_kernel<TriDGlobalP,false,2,false,4,false,false> (TSP100 x 1024, compact store, two register slots per lane)",
         "instructions_per_step": total_ins, "issue_cycles_per_step": total_cyc, "exposed_memory_cycles_per_step": exposed,
         "issue_model_cycles_per_step": total_cyc + exposed, "chain_floor_cycles_per_step": chain,
-        "measured_cycles_per_step_product_kernel_r05b": 4869,
+        "measured_cycles_per_step_product_kernel_r05c": 4883,
         "blocks": rows, "exposed": [{"what": w, "per_step": m, "cycles_each": c} for w, m, c in EXPOSED],
         "chain": [{"stage": s, "per_step": m, "cycles_each": sum(c for _, c in items), "items": [{"what": w, "cycles": c} for w, c in items]}
                   for s, m, items in CHAIN],
