@@ -235,3 +235,40 @@ def test_forward_with_saturated_attention(scale):
     assert np.isfinite(y).all()
     err, own = np.abs(y - ref64), np.abs(ref32 - ref64).max()
     assert (err <= RTOL * np.abs(ref64) + RTOL * np.abs(ref64).max()).all() or err.max() <= 3.0 * own, (err.max(), own)
+
+
+def test_feed_forward_block_paths_agree_and_fc_rides_in_the_block():
+    """The inference forward runs the feed-forward block on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six products)
+    with the next layer's fc (models.py:23) chained into the same launch: one gemm_fc launch per forward, not one per layer.  The
+    fp32 kernel (GNNGLS_FFN_FP32=1: read once per process, hence a child process) must give the same regret predictions to the
+    parity bar -- both approximate the same fp64 value (models.py:26-36,40)."""
+    import subprocess
+    import sys
+    import tempfile
+    from gnngls_amd import _lib, pipeline
+    from gnngls_amd.synthetic import random_instances
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, B = 40, 6
+    D = torch.from_numpy(random_instances(np.random.default_rng(3), B, n)[0]).cuda()
+    model = pipeline.synthetic_model(seed=1234)
+    sc = pipeline.Scalers.fit_weights(D)
+    _lib.profile_enable(True)
+    R = pipeline.predict_regret(model, D, sc)
+    torch.cuda.synchronize()
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    layers = prof["ffn_fused"][1]
+    assert layers >= 2 and prof["gemm_fc"][1] == (1 if os.environ.get("GNNGLS_FFN_FP32", "0") in ("", "0") else layers), prof
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "r.npy")
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+                "from gnngls_amd import pipeline\n"
+                "from gnngls_amd.synthetic import random_instances\n"
+                "D = torch.from_numpy(random_instances(np.random.default_rng(3), %d, %d)[0]).cuda()\n"
+                "R = pipeline.predict_regret(pipeline.synthetic_model(seed=1234), D, pipeline.Scalers.fit_weights(D))\n"
+                "np.save(%r, R.cpu().numpy())\n" % (root, B, n, out))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, GNNGLS_FFN_FP32="1"), timeout=600)
+        ref = np.load(out)
+    got = R.cpu().numpy()
+    off = ~np.eye(n, dtype=bool)
+    assert_regret_close(got[:, off], ref[:, off])
