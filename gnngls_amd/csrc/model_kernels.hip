@@ -1,4 +1,5 @@
-// model_kernels.hip -- edge-regret GNN forward on MI355X (gfx950), hand-written HIP, fp32.
+// model_kernels.hip -- edge-regret GNN forward on MI355X (gfx950), hand-written HIP, fp32 results (the feed-forward block of the
+// inference forward computes them on the bf16 matrix pipe from three bf16 pieces per fp32 operand: ffn_fused_bf16x3_kernel).
 //
 // Replaces (reference file:line, /root/reference/gnngls/...):
 //   models.py:44-70   EdgePropertyPredictionModel.forward
@@ -17,6 +18,8 @@
 //                           el/er are recomputed from the LDS tile (no [N,8] tensors in HBM); the
 //                           softmax shift is the exact row maximum (top-2 trick excludes k=j)
 //       (the log-sum-exp merge of the two row partials + skip + BN1 is fused into ffn_fused_kernel)
+//   K2b ffn_fused_bf16x3_kernel (inference) / ffn_fused_kernel (training, fp32 pipe): merge + BN1 + Linear/ReLU/Linear + skip + BN2
+//                           in one launch, the hidden layer never leaves the registers; the inference form also carries the next layer's fc
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <stdint.h>
@@ -759,7 +762,10 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 // W2p is the accumulator layout of GEMM1 (lane (row, q) holds hidden units 16 ht + 4 q + r of its row): as in the fp32 kernel
 // the hidden layer goes from the accumulators of GEMM1 through ReLU and the split straight into the B operand of GEMM2.
 // One workgroup = 128 rows, 8 wavefronts of 16 rows (two per SIMD), one workgroup per CU (142 KB of LDS: the x tile in fp32 for the
-// skip connection, split on the fly per k block; a ring of three 24 KB weight stages).
+// skip connection, split on the fly per k block; a ring of three 24 KB weight stages filled by LDS-DMA).  With the next layer's fc
+// weights given, four more stages chain ft = fc(h_out) (models.py:23 of layer l + 1) from the output's accumulator layout in the same
+// way and write it next to h_out: gemm_fc runs once per forward.  Measured at 1024 x TSP100 (profiles/r05_experiments/README.md):
+// 8.2 ms per launch including the fc against 11.2 + 1.8 ms of the fp32 kernels, 180 fp32-equivalent TFLOP/s; matrix pipe 50 % busy.
 // ---------------------------------------------------------------------------------------------
 #ifndef FFN_DBG
 #define FFN_DBG 0                    // bits: 1 no main loop, 2 no HBM traffic in the prologue / epilogue, 4 no weight streaming, 8 no MFMAs (time attribution builds)
