@@ -735,7 +735,9 @@ def main():
             "metric": f"TSP instances/sec + mean opt-gap @{args.time_limit:g}s, TSP{n}", "value": value, "unit": "instances/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f64 (search) / f32 (GNN)", "data": "synthetic",
+            "dtype": "f64 (search) / f32 (GNN)" if os.environ.get("GNNGLS_FFN_FP32", "0") not in ("", "0") else
+                     "f64 (search) / f32 (GNN; its feed-forward block as three bf16 pieces per f32 operand on the bf16 MFMA, f32 accumulate, f32-equivalent results)",
+            "data": "synthetic",
             "config": {"workload": (f"TSP{n}, fixed test set of {total} instances sharded over {world} GPU(s), GNN forward + "
                                     f"guided_local_search {args.time_limit:g} s budget "
                                     + ("per instance" if args.budget == "per_instance" else "per device-load sequence (rounds share it)")
