@@ -271,7 +271,13 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
     const int ns = n - 1;
     const int hb = (blockIdx.x % HG) * HS;                       // first head of this workgroup
     const int b = blockIdx.x / (n * HG), i = (blockIdx.x / HG) % n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifndef GAT_UNIFORM_WAVE
+#define GAT_UNIFORM_WAVE 1
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wavefront index as a SCALAR: the unit loop, the four source runs of a unit and their addresses' uniform parts then run on the
+    // scalar ALU with s_cbranch_scc loop ends instead of exec-masked loop control
+    const int wave = GAT_UNIFORM_WAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 4..8 waves, chosen by the launcher to balance the units
     float *ftS = reinterpret_cast<float *>(smem);            // [ns][LDF]
     float *elS = ftS + (size_t)ns * LDF;                     // [ns][HS]
