@@ -33,8 +33,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // packed fp32 (two lanes of work per instruction); the compiler scalarises <2 x float> arithmetic next to scalar selects
+#ifndef GAT_PACKED
+#define GAT_PACKED 0            // 1: v_pk_mul_f32 / v_pk_add_f32 on head pairs (round 2: +2 % with the weight arithmetic of that round; round 5, with the maximum form: 5.07 -> 4.95 ms WITHOUT packing)
+#endif
+#if GAT_PACKED
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#else
+// (A/B: two single instructions per pair -- MI355X_MICROARCH.md prices a packed f32 instruction beside MFMAs above two plain ones)
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    float d0, d1;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d0) : "v"(a[0]), "v"(b[0]));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(d1) : "v"(a[1]), "v"(b[1]));
+    return f32x2{d0, d1};
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    float d0, d1;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d0) : "v"(a[0]), "v"(b[0]));
+    asm("v_add_f32 %0, %1, %2" : "=v"(d1) : "v"(a[1]), "v"(b[1]));
+    return f32x2{d0, d1};
+}
+#endif
 // one v_max_f32: fmaxf() on values that come out of inline asm gets a canonicalising v_max_f32 x, x, x per operand first
 // (three instructions per maximum)
 __device__ __forceinline__ float max_f32(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
