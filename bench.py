@@ -243,60 +243,49 @@ def search_roofline(n, steps, gls_ms, gls_launches, ref_evals, exec_ratio, resid
     matches = bool(traffic.get("workload")) and all(traffic["workload"].get(k) == v for k, v in workload.items())
     busy = {k[:-len("_busy_frac")]: traffic[k] for k in traffic if k.endswith("_busy_frac") and traffic[k] is not None}
     order = sorted(busy, key=busy.get, reverse=True)
-    clock = traffic.get("clock_ghz")
-    valu = busy.get("valu") if matches else None             # counters of another workload say nothing about this one
-    wait = traffic.get("wave_wait_frac") if matches else None
-    # what binds the kernel, from the counters: no pipe more than 60 % busy while the wavefronts wait more than half of their
-    # resident cycles = the dependent chains of single wavefronts ("latency"); else the busiest pipe's issue rate
-    if order and matches:
-        bound = "latency" if busy[order[0]] <= 0.6 and wait is not None and wait > 0.5 else order[0] + "_issue"
-    else:
-        # no counters on this workload: the design statement (the kernel runs at the pace of the dependent
-        # chains of single wavefronts; the headline's counters say the same)
-        bound = "latency"
-    bound_source = "PMC counters of this workload (pmc)" if order and matches else "design: no PMC pass on this workload"
     crit = critical_path(n, cyc)
-    if crit and crit["frac"] is not None:
-        # primary fraction, measured in THIS run: penalty steps per second of an instance against the rate its dependent chain allows
-        ach, peak, unit, frac = crit["clock_ghz"] * 1e9 / crit["measured_cycles"], crit["clock_ghz"] * 1e9 / crit["floor_cycles"], \
-            "penalty steps/s per instance", crit["frac"]
-        frac_source = "measured in this run (critical_path: committed chain floor / measured cycles per penalty step)"
-    else:
-        # no chain model for this size: the busy fraction of the vector ALUs of the committed PMC passes (not of this run)
-        ach, peak, unit, frac = (valu * N_SIMDS * clock if valu is not None and clock else None), (N_SIMDS * clock if clock else None), \
-            "G SIMD-cycles/s", valu
-        frac_source = ("committed PMC pass, not this run: %s" % traffic.get("source")) if valu is not None else None
+    # PRIMARY fraction, frozen from round 6 on (the round-5 review: "a roofline statement that means the same thing two rounds in a
+    # row"): SURVEY 8(d)'s K3 figure -- algorithmic LDS bytes of the EXECUTED delta evaluations (48 B per 2-opt, 68 B per relocate
+    # evaluation) per second of the dominant kernel's launches, against the aggregate LDS rate of the device.  Measured in this
+    # run: HIP events around the timed launches x the kernel's own evaluation counter x the executed / reference-equivalent ratio
+    # of the counting pass.  The exact pruning of the descent scans LOWERS it while the search gets faster (fewer evaluations for
+    # the same moves), so outer iterations per budget stay the figure of merit beside it.
+    exec_ratio_is_one = n < 80                               # no descent scan prunes below n = 80 (gls_prune_supported): executed = reference
+    lds_rate = exec_rate if exec_rate is not None else (ref_rate if exec_ratio_is_one else None)
+    ach = lds_rate * lds_bytes_per_eval / 1e9 if lds_rate is not None else None
+    frac = ach / PEAK_LDS_GBS if ach is not None else None
     out = {
-        "kernel": "gls_kernel", "bound": bound, "bound_source": bound_source,
-        "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "frac_source": frac_source,
-        "critical_path": crit,
+        "kernel": "gls_kernel", "bound": "lds",
+        "achieved": ach, "peak": PEAK_LDS_GBS, "unit": "GB/s", "frac": frac,
+        "frac_definition": "SURVEY 8(d), K3: executed delta evaluations per second of the gls_kernel launches (timed steps, HIP events) x "
+                           "their algorithmic LDS bytes (48 B per 2-opt, 68 B per relocate evaluation) / aggregate LDS rate "
+                           "(256 CUs x 128 B/clk x 2.4 GHz).  Same definition every round from round 6 on; r01-r05 recomputed: "
+                           "0.22 / 0.305 / 0.33 (reference-equivalent, nothing pruned yet) / 0.231 / 0.293",
+        "frac_source": "measured in this run" if frac is not None else None,
         "traffic": traffic["hbm_bytes_per_instance_second"] * resident * avg_launch_s
         if matches and "hbm_bytes_per_instance_second" in traffic else None,
         "avg_launch_ms": avg_launch_s * 1e3, "launches": int(gls_launches), "resident_instances": resident,
         "executed_evals_per_s": exec_rate, "reference_equivalent_evals_per_s": ref_rate,
         "prune_ratio": exec_ratio,
         "lds_bytes_per_eval": lds_bytes_per_eval,
-        "lds_executed": {"achieved": exec_rate * lds_bytes_per_eval / 1e9, "peak": PEAK_LDS_GBS, "unit": "GB/s",
-                         "frac": exec_rate * lds_bytes_per_eval / 1e9 / PEAK_LDS_GBS} if exec_rate is not None else None,
         "reference_equivalent_frac": ref_rate * lds_bytes_per_eval / 1e9 / PEAK_LDS_GBS,
         "delta_evals_per_s": ref_rate,
+        # side records, none of them the fraction: the serial phase against its dependent-chain floor and the descent scans against
+        # their issue model (critical_path), the committed counters of this workload (pmc) and its two busiest pipes -- no label
+        "critical_path": crit,
         "pmc": {k: traffic[k] for k in ("valu_busy_frac", "lds_busy_frac", "lds_bank_conflict_frac", "wave_wait_frac",
                                         "valu_insts_per_s", "lds_insts_per_s", "hbm_gbs", "clock_ghz", "workload", "source")
-                if k in traffic},
-        # the busiest pipes according to those counters (null without counters)
-        "binding_resource": {"name": (order[0] + "_issue") if order and matches else None,
-                             "frac": busy[order[0]] if order and matches else None,
-                             "second": order[1] if len(order) > 1 and matches else None,
-                             "second_frac": busy[order[1]] if len(order) > 1 and matches else None},
+                if k in traffic} if matches else None,
+        "busiest_pipes": [{"pipe": k, "busy_frac": busy[k]} for k in order[:2]] if order and matches else None,
+        "wave_wait_frac": traffic.get("wave_wait_frac") if matches else None,
         "pmc_matches_workload": matches,
-        "note": "frac = critical_path.frac where a chain model of this size is committed (else the busy fraction of the vector ALUs of "
-                "the committed PMC passes, `pmc`; frac_source says which).  reference_equivalent_evals_per_s is "
-                "measured on the timed launches (HIP events + the kernel's counter of what the reference evaluates); prune_ratio = "
-                "executed / reference-equivalent evaluations of a %g s untimed pass of the same workload on the counting "
-                "instantiation of the kernel (the pruned descent scans -- 2-opt from n = 80, relocate from n = 128 -- evaluate only "
-                "the moves that can qualify); executed_evals_per_s and lds_executed are their product.  reference_equivalent_frac = "
-                "the algorithmic LDS figure of rounds 1-3 (a work rate: 1 / prune_ratio above the executed one).  The forward "
-                "kernels' MFMA / HBM rooflines are under `kernels`" % COUNT_PASS_S,
+        "note": "reference_equivalent_evals_per_s is measured on the timed launches (HIP events + the kernel's counter of what the "
+                "reference evaluates); prune_ratio = executed / reference-equivalent evaluations of a %g s untimed pass of the same "
+                "workload on the counting instantiation of the kernel (pruned 2-opt scan from n = 80, quiet rows of the relocate scan for "
+                "80 <= n <= 127, pruned relocate scan from n = 128: exact, they evaluate only the moves that can qualify); "
+                "executed_evals_per_s is their product.  reference_equivalent_frac = the same LDS figure for every move the reference "
+                "evaluates (a work rate: 1 / prune_ratio above the executed one).  The forward kernels' MFMA / HBM rooflines are "
+                "under `kernels`" % COUNT_PASS_S,
     }
     return out
 
@@ -691,8 +680,10 @@ def main():
             from oracle import one_tree
             m = min(B, 1024)
             lb = one_tree.lower_bounds(D_host[:m], g[:m, 0], workers=available_cores())
-            assert (lb <= bk[:m] * (1 + 1e-9)).all(), "1-tree bound above a known tour length"
-            bracket = {"vs_best_known_pct": float(gap[:m].mean()), "vs_lower_bound_pct": float(((g[:m, 0] / lb - 1.0) * 100.0).mean()),
+            # a lower bound above a known tour length would be a checker bug: reported in the line, never a reason to discard the run
+            bad_bound = int((lb > bk[:m] * (1 + 1e-9)).sum())
+            bracket = {"bound_above_known_tour_instances": bad_bound,
+                       "vs_best_known_pct": float(gap[:m].mean()), "vs_lower_bound_pct": float(((g[:m, 0] / lb - 1.0) * 100.0).mean()),
                        "instances": int(m), "best_known_above_lower_bound_pct": float(((bk[:m] / lb - 1.0) * 100.0).mean()),
                        "how": "mean over the instances of (best_cost / x - 1) * 100 with x = best-known tour length (>= optimum) "
                               "and x = Held-Karp 1-tree lower bound (<= optimum, subgradient ascent, oracle/one_tree.c)"}

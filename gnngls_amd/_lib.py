@@ -33,6 +33,9 @@ SIGNATURES = {
     "gnngls_model_packed_floats": [_int, _int],
     "gnngls_regret_forward_workspace_bytes": [_int, _int],
     "gnngls_regret_forward": [_vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
+    "gnngls_regret_prepared_bytes": [_int],
+    "gnngls_regret_prepare": [_vp, _int, _int, _vp, _i64, _vp],
+    "gnngls_regret_forward_prepared": [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
     "gnngls_regret_train_workspace_bytes": [_int, _int, _int],
     "gnngls_regret_train_forward": [_vp, _vp, _int, _int, _int, _int, _f32, _vp, _vp, _vp, _i64, _vp],
     "gnngls_regret_train_backward": [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _i64, _vp],
@@ -69,8 +72,10 @@ def profile_collect():
     return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_KINDS)}
 _RESTYPES = {"gnngls_last_error": ctypes.c_char_p, "gnngls_model_packed_floats": ctypes.c_int64,
              "gnngls_regret_forward_workspace_bytes": ctypes.c_int64,
+             "gnngls_regret_prepared_bytes": ctypes.c_int64,
              "gnngls_regret_train_workspace_bytes": ctypes.c_int64}
 
+_ABI4 = ("gnngls_regret_prepared_bytes", "gnngls_regret_prepare", "gnngls_regret_forward_prepared")
 _lib = None
 
 
@@ -93,6 +98,8 @@ def load():
         import torch  # noqa: F401
         L = ctypes.CDLL(SO)
         for name, argtypes in SIGNATURES.items():
+            if name in _ABI4 and "GNNGLS_HIP_SO" in os.environ and not hasattr(L, name):
+                continue              # an older build of the library named by GNNGLS_HIP_SO (same-box A/B of kernel variants)
             f = getattr(L, name)      # AttributeError if the symbol is missing
             f.argtypes = argtypes
             f.restype = _RESTYPES.get(name, ctypes.c_int)

@@ -176,7 +176,7 @@ GlsConfig gls_config_store(int n, int requested_bits, int batch, bool first_impr
 
 extern "C" {
 
-int gnngls_abi_version(void) { return 3; }
+int gnngls_abi_version(void) { return 4; }
 const char *gnngls_last_error(void) { return g_err; }
 
 int gnngls_gls_resident_capacity(int n) {
@@ -392,8 +392,31 @@ int64_t gnngls_regret_forward_workspace_bytes(int B, int n) {
     return (int64_t)B * N * kBytesPerNode + 256;
 }
 
-int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
-                          float *y_out, void *workspace, int64_t workspace_bytes, void *stream) {
+int64_t gnngls_regret_prepared_bytes(int n_layers) {
+    if (n_layers < 0) return 0;
+    return (int64_t)n_layers * (int64_t)gnngls::ffn_packed_bytes() + 256;
+}
+
+int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *prepared, int64_t prepared_bytes, void *stream) {
+    if (!weights || !prepared || in_dim < 1 || n_layers < 0) return fail(GNNGLS_ERR_ARG, "regret_prepare: bad argument");
+    if (prepared_bytes < gnngls_regret_prepared_bytes(n_layers))
+        return fail(GNNGLS_ERR_ARG, "regret_prepare: buffer too small (%lld B, need %lld B)", (long long)prepared_bytes,
+                    (long long)gnngls_regret_prepared_bytes(n_layers));
+    unsigned char *base = (unsigned char *)(((uintptr_t)prepared + 255) & ~(uintptr_t)255);
+    const float *layers = weights + 128L * in_dim + 128;
+    for (int l = 0; l < n_layers; ++l) {
+        const float *w = layers + (long)l * kLayerFloats;
+        const float *w1 = w + 128L * 128 + 4 * 128, *w2 = w1 + 512L * 128 + 512;
+        const float *fc_next = l + 1 < n_layers ? layers + (long)(l + 1) * kLayerFloats : nullptr;
+        hipError_t e = gnngls::launch_ffn_pack(w1, w2, fc_next, base + (size_t)l * gnngls::ffn_packed_bytes(), (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "regret_prepare");
+    }
+    return GNNGLS_OK;
+}
+
+int gnngls_regret_forward_prepared(const float *feat, const float *weights, const void *prepared, int64_t prepared_bytes,
+                                   int B, int n, int in_dim, int n_layers,
+                                   float *y_out, void *workspace, int64_t workspace_bytes, void *stream) {
     if (B == 0) return GNNGLS_OK;   // empty batch: nothing to enqueue (data pointers may be NULL)
     if (!feat || !weights || !y_out || !workspace || B < 0 || n < 3 || in_dim < 1 || n_layers < 0)
         return fail(GNNGLS_ERR_ARG, "regret_forward: bad argument");
@@ -401,6 +424,12 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     if (gnngls::gat_rows_lds_bytes(n) > kLdsPerCU)
         return fail(GNNGLS_ERR_UNSUPPORTED, "regret_forward: n=%d needs %zu B of LDS per row tile (> 160 KiB)", n,
                     gnngls::gat_rows_lds_bytes(n));
+    // prepared == NULL keeps the feed-forward block on the fp32 matrix pipe (as GNNGLS_FFN_FP32=1 does: A/B runs)
+    static const bool ffn_fp32 = getenv("GNNGLS_FFN_FP32") && atoi(getenv("GNNGLS_FFN_FP32")) != 0;
+    if (prepared && prepared_bytes < gnngls_regret_prepared_bytes(n_layers))
+        return fail(GNNGLS_ERR_ARG, "regret_forward: prepared image too small (%lld B, need %lld B)", (long long)prepared_bytes,
+                    (long long)gnngls_regret_prepared_bytes(n_layers));
+    const unsigned char *prep = (prepared && !ffn_fp32) ? (const unsigned char *)(((uintptr_t)prepared + 255) & ~(uintptr_t)255) : nullptr;
     const long N = (long)n * (n - 1) / 2;
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     int64_t avail = workspace_bytes - (int64_t)(base - (uintptr_t)workspace);
@@ -419,18 +448,6 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     const float *layers = emb_b + 128;
     const float *dec_w = layers + (long)n_layers * kLayerFloats, *dec_b = dec_w + 128;
     hipError_t e = hipSuccess;
-    // scratch for one layer's split weights (the bf16x3 form of the feed-forward block), stream-ordered like gls_run's;
-    // GNNGLS_FFN_FP32=1 keeps the block on the fp32 matrix pipe (A/B runs)
-    struct StreamScratch {
-        void *p = nullptr; hipStream_t st;
-        ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
-    } ffn_ws;
-    ffn_ws.st = st;
-    static const bool ffn_fp32 = getenv("GNNGLS_FFN_FP32") && atoi(getenv("GNNGLS_FFN_FP32")) != 0;
-    if (n_layers > 0 && !ffn_fp32) {
-        e = hipMallocAsync(&ffn_ws.p, gnngls::ffn_packed_bytes(), st);
-        if (e != hipSuccess) { ffn_ws.p = nullptr; return hip_fail(e, "regret_forward: scratch alloc"); }
-    }
 #define GNNGLS_TRY(x) do { e = (x); if (e != hipSuccess) return hip_fail(e, #x); } while (0)
     for (long b0 = 0; b0 < B; b0 += Bc) {
         const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
@@ -445,15 +462,15 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
             const float *bn2_s = b2 + 128, *bn2_b = bn2_s + 128;
             // ft = fc(h), models.py:23: a launch of its own for the first layer (and for every layer on the fp32 path); on the bf16x3 path
             // the feed-forward launch of layer l - 1 has already written it (fc folded into that kernel's tail)
-            if (l == 0 || !ffn_ws.p) {
+            if (l == 0 || !prep) {
               ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
             // gat_combine + FFN1 + FFN2 (+ the next layer's fc) in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
-              const float *fc_next = (ffn_ws.p && l + 1 < n_layers) ? layers + (long)(l + 1) * kLayerFloats : nullptr;
-              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M, ffn_ws.p, fc_next, ft, st)); }
+              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M,
+                                                  prep ? prep + (size_t)l * gnngls::ffn_packed_bytes() : nullptr, prep && l + 1 < n_layers, ft, st)); }
             { float *x = h; h = h2; h2 = x; }
         }
         { ProfScope ps(GNNGLS_PROF_DECISION, st);
@@ -461,6 +478,30 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
     }
 #undef GNNGLS_TRY
     return GNNGLS_OK;
+}
+
+// The one-call form: splits the weights into stream-ordered scratch of its own on every call (gnngls_regret_prepare +
+// gnngls_regret_forward_prepared keep the image across calls: 2 launches per layer and the allocation saved per forward).
+int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
+                          float *y_out, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (B == 0) return GNNGLS_OK;
+    if (!feat || !weights || !y_out || !workspace || B < 0 || n < 3 || in_dim < 1 || n_layers < 0)
+        return fail(GNNGLS_ERR_ARG, "regret_forward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    struct StreamScratch {
+        void *p = nullptr; hipStream_t st;
+        ~StreamScratch() { if (p) (void)hipFreeAsync(p, st); }
+    } ffn_ws;
+    ffn_ws.st = st;
+    static const bool ffn_fp32 = getenv("GNNGLS_FFN_FP32") && atoi(getenv("GNNGLS_FFN_FP32")) != 0;
+    const int64_t pb = gnngls_regret_prepared_bytes(n_layers);
+    if (n_layers > 0 && !ffn_fp32) {
+        hipError_t e = hipMallocAsync(&ffn_ws.p, (size_t)pb, st);
+        if (e != hipSuccess) { ffn_ws.p = nullptr; return hip_fail(e, "regret_forward: scratch alloc"); }
+        const int rc = gnngls_regret_prepare(weights, in_dim, n_layers, ffn_ws.p, pb, stream);
+        if (rc != GNNGLS_OK) return rc;
+    }
+    return gnngls_regret_forward_prepared(feat, weights, ffn_ws.p, pb, B, n, in_dim, n_layers, y_out, workspace, workspace_bytes, stream);
 }
 
 int gnngls_pack_features(const double *D, int B, int n, double scale, double min_, float *feat, void *stream) {

@@ -47,7 +47,7 @@ constexpr int kGuidePassesMax = 4;   // register-cached guide values cover n <= 
 // a side buffer that nothing else reads.  The shipped library is built without it.
 struct Stamps {
 #ifdef GLS_STAMPS
-    long long acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 20..23: quiet rows (reduced scans, their cycles, update cycles, active rows)
     long long t0 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
     __device__ __forceinline__ void end(int i) { const long long n = clock64(); acc[i] += n - t0; t0 = n; }
@@ -62,6 +62,13 @@ struct Stamps {
 #define STAMP_BEGIN() st.begin()
 #define STAMP_END(i) st.end(i)
 #define STAMP_COUNT(i) st.count(i)
+
+// -DGLS_ISA_MARKS (scripts/isa_critical_path.py): comment lines in the disassembly that delimit the regions of a penalty step
+#ifdef GLS_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; GLSMARK " name)
+#else
+#define ISA_MARK(name) do {} while (0)
+#endif
 
 __device__ __forceinline__ int make_key(int i, int j) { return (i << 16) | j; }
 

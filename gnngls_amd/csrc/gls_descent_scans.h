@@ -343,6 +343,224 @@ __device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, 
     }
 }
 
+// ---- quiet rows of the relocate descent scan (best improvement, symmetric stores, 80 <= n <= 127 with neighbour lists on) ------
+// relocate_a2a (operators.py:129-147) returns the lexicographic minimum of (delta, i, j) over the QUALIFYING moves (delta < 0 and
+// not np.isclose(0, delta): delta < -1.00001e-8).  A candidate is (node b with its tour neighbours a, c; target tour edge {d, e}):
+//     delta = (((((-D[a,b]) - D[b,c]) + D[a,c]) - D[d,e]) + D[d,b]) + D[b,e]
+// As a real number it depends on the UNORDERED neighbour pair and the UNORDERED target edge only; the five roundings move it by
+// < 2.2e-15 max|D|, so two evaluations of the same candidate in different operand orders (a reversed segment) differ by
+// < 4.4e-9 for max|D| <= 1e6 (prune_ok, neighbor_lists_kernel).  Hence: a row b ALL of whose candidates -- every tour edge but
+// its own two, the one the reference skips for orientation (i - j == 1) included -- evaluated >= kQuietThr = -2.5e-9 has no
+// qualifying move (>= -6.9e-9 in any order) until either its neighbours change or an edge enters the tour that was not there
+// when the row was evaluated.  One flag per node says "this row may hold a qualifying move":
+//   * the first relocate scan of a descent is the full lean scan; it flags every row with a delta < kQuietThr (LDS bit mask);
+//   * every accepted move of the descent appends its 2 or 3 NEW tour edges to a pending list and flags their endpoints (thread 0);
+//   * the following relocate scans first REFRESH: node b = 1 + nwaves l + w belongs to lane l of wavefront w for the whole descent;
+//     the lane recomputes the row constants of its node on the current tour and evaluates the pending edges for it (one candidate
+//     per row and edge, 5 n evaluations at most, not n^2); endpoints of pending edges are flagged (their neighbours changed) --
+//     then evaluate the flagged rows only, in full, with the reference's operand order and keys -- the arg-min over a superset
+//     of the qualifying moves is the reference's arg-min -- and drop the flags of rows found quiet.  Flags are wave-private.
+// With the bench's guide ~10 of 99 rows are flagged from the second relocate scan of a descent on (simulated on the oracle's
+// trajectory: identical moves in 300 outer iterations x 3 guides, profiles/r06_experiments/quiet_rows_simulation.txt).
+#ifndef GLS_QUIET_ROWS
+#define GLS_QUIET_ROWS 1
+#endif
+constexpr double kQuietThr = -2.5e-9;
+constexpr int kQuietPendCap = 5;        // new tour edges between two relocate scans: <= 3 (relocate move) + 2 (2-opt move)
+// LDS of the scheme, in exchange slots the best-improvement descent does not use (bytes 24 .. 119 of Ctl::red_d -- the pruned relocate
+// scan's long-edge list lives there in the 4-slot builds, which do not run this -- and one int of red_k):
+//   words: bit q of word w <-> node 1 + 64 w + q: rows to flag at the next refresh (the full scan's result, the endpoints of new edges)
+//   pend:  the new tour edges since the last relocate scan, ready for the refresh (thread 0 does the index arithmetic ONCE per move
+//          instead of every wavefront per refresh): row address terms of x and y for tri_addr_max, the LDS address of D[x,y], 8x | 8y << 16
+struct QuietPend { int xr, yr, laddr, x8y8; };
+struct QuietLds {
+    unsigned long long words[2];
+    QuietPend pend[kQuietPendCap];
+};
+static_assert(sizeof(QuietLds) == 96, "red_d[0][3] .. red_d[1][6]");
+__device__ __forceinline__ QuietLds *quiet_lds(Ctl *ctl) { return reinterpret_cast<QuietLds *>(&ctl->red_d[0][3]); }
+__device__ __forceinline__ int *quiet_count(Ctl *ctl) { return &ctl->red_k[0][3]; }
+// start of a descent (thread 0): nothing flagged, nothing pending; every record holds addresses inside the distance triangle
+__device__ __forceinline__ void quiet_reset(QuietLds *q, int *count, int dbase) {
+    q->words[0] = 0ull; q->words[1] = 0ull; *count = 0;
+    for (int e = 0; e < kQuietPendCap; ++e) q->pend[e] = QuietPend{dbase, dbase, dbase, 0};
+}
+__device__ __forceinline__ void quiet_set(unsigned long long *qmask, int node) {
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+    __hip_atomic_fetch_or((lds_u64_t *)(qmask + ((node - 1) >> 6)), 1ull << ((node - 1) & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// the new tour edges of an accepted move, from the OLD tour, beside apply_move -- by lanes 0 .. 2 of the workgroup's LAST wavefront,
+// which has no tour position to move for n <= 64 (nwaves - 1) (one thread doing all of it was ~1,000 cycles in front of the barrier
+// every other wavefront waits at):
+//   2-opt (i < j): adds (t[i-1],t[j-1]), (t[i],t[j])                       (operators.py:6-11)
+//   relocate:      adds (a,c), (d,b), (b,e)                                 (operators.py:76-80, 91-96)
+// Their endpoints are the nodes whose neighbours change: flagged through `words` (LDS atomics: several lanes may hit one word).
+template <class TT>
+__device__ __forceinline__ void quiet_note_move(QuietLds *q, int *count, int dbase, const TT *told, int op, int i, int j, int lane) {
+    const int c0 = *count;                                   // uniform
+    const int npairs = op == 0 ? 2 : 3;
+    if (lane < npairs && c0 + lane < kQuietPendCap) {
+        int x, y;
+        if (op == 0) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            x = told[lo - 1 + lane]; y = told[hi - 1 + lane];                      // lane 0: (t[lo-1], t[hi-1]); lane 1: (t[lo], t[hi])
+        } else {
+            const int jd = i < j ? j : j - 1;                                      // (d, e) = (t[jd], t[jd+1])
+            // lane 0: (a, c) = (t[i-1], t[i+1]); lane 1: (d, b) = (t[jd], t[i]); lane 2: (b, e) = (t[i], t[jd+1])
+            x = told[lane == 0 ? i - 1 : lane == 1 ? jd : i];
+            y = told[lane == 0 ? i + 1 : lane == 1 ? i : jd + 1];
+        }
+        const int hi = x > y ? x : y, lo = x > y ? y : x;
+        // (x or y may be the depot: kNoRow makes the lane's own row term win in tri_addr_max -- D[b,0] is the first entry of row b)
+        q->pend[c0 + lane] = QuietPend{x == 0 ? kNoRow : dbase + 4 * x * (x - 1), y == 0 ? kNoRow : dbase + 4 * y * (y - 1),
+                                       dbase + 4 * hi * (hi - 1) + 8 * lo, (8 * x) | ((8 * y) << 16)};
+        if (x >= 1) quiet_set(q->words, x);
+        if (y >= 1) quiet_set(q->words, y);
+    }
+    if (lane == 0) *count = c0 + npairs;                     // (> kQuietPendCap cannot happen between two relocate scans; the refresh checks anyway)
+}
+
+// Per-lane state of the scheme across the scans of a descent: the flag of the lane's node (node 1 + nwaves l + w, fixed)
+struct QuietLane {
+    bool act;            // the row of this lane's node may hold a qualifying move
+};
+
+// Refresh + reduced relocate scan of one wavefront (see above).  Returns false if the pending list overflowed: the caller runs
+// the full scan instead (cannot happen with one 2-opt and one relocate move between two relocate scans).
+// At four wavefronts per SIMD every instruction of a wavefront costs ~6-15 cycles whatever it is (profiles/r06_experiments/
+// quiet_rows.md: the first version of this function was 717 instructions for 2.4 rows and took 4.5k cycles -- 60 % of the full
+// lean scan it replaces), so both parts are written for instruction count: pending pairs and the row terms of the uniform node on
+// the scalar unit, packed-triangle addresses in the select-free max form (tri_addr_max), the endpoints of the pending edges as a
+// scalar bit mask, the row constants of a flagged row by v_readlane from the lane that owns its node.
+template <bool CNT, class S, class TT>
+__device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t, const TT *pos, const double *Ef, int n,
+                                                        const QuietLds *q, const int *qcount, QuietLane &me,
+                                                        int wave, int nwaves, int lane, double &bd, int &bk, int &xe) {
+    const int dbase = lds_byte_addr(s.d);
+    ISA_MARK("quiet_refresh_begin");
+    // level 0 reads: the pending records and their count, the rows to flag, the lane's node position, the lane's target edges
+    const int npend = __builtin_amdgcn_readfirstlane(*qcount);
+    const int wsh = nwaves == 2 ? 1 : nwaves == 4 ? 2 : nwaves == 8 ? 3 : 4;      // log2(nwaves): 2 .. 16 wavefronts
+    const int b = 1 + (lane << wsh) + wave;                  // lane l <-> node b = 1 + nwaves l + wave
+    const bool mine = b <= n - 1;
+    const int bc = mine ? b : 1;
+    const int i = pos[bc];
+    const unsigned long long flagword = q->words[(bc - 1) >> 6];
+    int dnode[2], enode[2];
+    double len[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int k = lane + p * kWave;
+        const bool ok = k <= n - 1;
+        const int kc = ok ? k : 0;
+        dnode[p] = t[kc]; enode[p] = t[kc + 1];
+        len[p] = ok ? Ef[kc + 1] : -__builtin_inf();         // dead lanes: delta = +inf
+    }
+    if (npend > kQuietPendCap) return false;                 // uniform
+    // level 1: the row's neighbours and edge lengths; the pending edges' lengths and the row's distances to their endpoints
+    const int a = t[i - 1], c = t[i + 1];
+    const double eab = Ef[i], ebc = Ef[i + 1];
+    const int bXl = opaque_vgpr(dbase + 4 * bc * (bc - 1)), b8l = opaque_vgpr(8 * bc);      // row address terms of the lane's node (b >= 1)
+    // pending edges in two batches (3 + 2: the registers of five candidates in flight at once spill): per record one broadcast
+    // 16-byte read, then D[x,y], D[x,b], D[b,y] (records past npend are stale or quiet_reset's: valid addresses, evaluated and
+    // masked out -- no branches; the lanes of an edge's endpoints read garbage: they are flagged through `words`)
+    unsigned long long hitm0 = 0ull;                         // scalar
+    double base = 0.0;
+    auto batch = [&](auto first, auto count_, bool with_base) {
+        constexpr int E0 = decltype(first)::value, EN = decltype(count_)::value;
+        double lxy[EN], dxb[EN], dby[EN];
+#pragma unroll
+        for (int e = 0; e < EN; ++e) {
+            const int4 rec = *reinterpret_cast<const int4 *>(&q->pend[E0 + e]);      // uniform address
+            const int x8 = rec.w & 0xffff, y8 = (int)((unsigned)rec.w >> 16);
+            lxy[e] = lds_read_f64(rec.z);
+            dxb[e] = lds_read_f64(tri_addr_max(bXl, b8l, rec.x, x8));
+            dby[e] = lds_read_f64(tri_addr_max(bXl, b8l, rec.y, y8));
+        }
+        if (with_base) {                                     // level 2 of the row constants, under the first batch's reads
+            const double dac = s.dist(a, c);
+            base = -eab;                                     // -D[a,b]          (operators.py:97-99, left to right)
+            base = base - ebc;                               // -D[b,c]
+            base = base + dac;                               // +D[a,c]
+        }
+#pragma unroll
+        for (int e = 0; e < EN; ++e) {
+            double d = base - lxy[e];
+            d = d + dxb[e];
+            d = d + dby[e];
+            const unsigned long long m = __ballot(d < kQuietThr);
+            hitm0 |= E0 + e < npend ? m : 0ull;
+        }
+    };
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, true);
+    batch(std::integral_constant<int, 3>{}, std::integral_constant<int, kQuietPendCap - 3>{}, false);
+    const bool hit = ((hitm0 >> lane) & 1ull) != 0ull || ((flagword >> ((bc - 1) & 63)) & 1ull) != 0ull;
+    if constexpr (CNT) xe += npend * __popcll(__ballot(mine));
+    me.act = me.act || (mine && hit);
+    ISA_MARK("quiet_refresh_end");
+
+    // ---- reduced scan: lane l holds target edges k = l and l + 64 -- (d, e) = (t[k], t[k+1]) with their packed row addresses
+    // and D[d,e] in registers --; a row is two passes of two random LDS reads, three fp64 adds, two compares ----
+    unsigned long long rows = __ballot(me.act);
+    if (!rows) return true;
+    int dx[2], d8[2], ex[2], e8[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int d = dnode[p], e = enode[p];
+        // tri_addr_max: the depot (position 0 / n only) passes kNoRow so that the row's own address term wins
+        dx[p] = opaque_vgpr(d == 0 ? kNoRow : dbase + 4 * d * (d - 1)); d8[p] = opaque_vgpr(8 * d);
+        ex[p] = opaque_vgpr(e == 0 ? kNoRow : dbase + 4 * e * (e - 1)); e8[p] = opaque_vgpr(8 * e);
+    }
+    const int live1 = n - kWave > 0 ? n - kWave : 0;         // live lanes of the second pass (k = 64 .. n-1)
+    const long long basebits = __double_as_longlong(base);
+    const int klane1 = lane + 1;                             // k - i + 1 = klane1 - i for the first pass, + 64 for the second
+    unsigned long long quiet = 0ull;                         // rows found quiet
+    ISA_MARK("quiet_row_loop");
+    while (rows) {
+        const int l = __ffsll((long long)rows) - 1;
+        rows &= rows - 1;
+        // the row's constants from the lane that owns its node
+        const int ri = __builtin_amdgcn_readlane(i, l);
+        const int bX = __builtin_amdgcn_readlane(bXl, l), b8 = __builtin_amdgcn_readlane(b8l, l);
+        const double rbase = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(basebits >> 32), l) << 32) |
+                                                  (unsigned)__builtin_amdgcn_readlane((int)basebits, l));
+        const double vd0 = lds_read_f64(tri_addr_max(dx[0], d8[0], bX, b8));      // D[d,b]  (garbage on the lanes k in {i-1, i}: masked below)
+        const double ve0 = lds_read_f64(tri_addr_max(ex[0], e8[0], bX, b8));      // D[b,e]
+        const double vd1 = lds_read_f64(tri_addr_max(dx[1], d8[1], bX, b8));      // (second pass: dead lanes read a valid address, their delta is +inf)
+        const double ve1 = lds_read_f64(tri_addr_max(ex[1], e8[1], bX, b8));
+        double delta0 = rbase - len[0];                      // -D[d,e]          (operators.py:100-102, left to right)
+        delta0 = delta0 + vd0;                               // +D[d,b]
+        delta0 = delta0 + ve0;                               // +D[b,e]
+        double delta1 = rbase - len[1];
+        delta1 = delta1 + vd1;
+        delta1 = delta1 + ve1;
+        // quiet test: every target edge but the row's own two, k in {i-1, i}  <=>  (unsigned)(k - i + 1) < 2
+        const unsigned u0 = (unsigned)(klane1 - ri);
+        const unsigned long long own0 = __ballot(u0 < 2u), own1 = __ballot(u0 + (unsigned)kWave < 2u);
+        const unsigned long long hitm = (__ballot(delta0 < kQuietThr) & ~own0) | (__ballot(delta1 < kQuietThr) & ~own1);
+        if constexpr (CNT) xe += (n < kWave ? n : kWave) + live1;
+        if (min_f64_raw(delta0, delta1) <= bd) {
+            rare_path();
+            ISA_MARK("quiet_row_rare");
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const double delta = p ? delta1 : delta0;
+                const int kk = lane + p * kWave;
+                // valid targets: k not in {i-2, i-1, i} (operators.py:133-136: i - j == 1 <=> k = i - 2)
+                if (delta <= bd && (unsigned)(kk - ri + 2) > 2u && !close_to_zero(delta)) {
+                    const int key = make_key(ri, kk < ri ? kk + 1 : kk);
+                    if (delta < bd || key < bk) { bd = delta; bk = key; }
+                }
+            }
+        }
+        ISA_MARK("quiet_row_tail");
+        if (!hitm) quiet |= 1ull << l;
+    }
+    ISA_MARK("quiet_scan_end");
+    if ((quiet >> lane) & 1ull) me.act = false;
+    return true;
+}
+
 // pos != nullptr: lane l of row block rb owns NODE b = 1 + 64 rb + l (wherever it sits in the tour: i = pos[b]) instead of
 // tour POSITION 1 + 64 rb + l.  The random read of a step is D[b, e] with e wave-uniform: with consecutive node ids on the
 // lanes the half of the lanes with b < e reads 64 consecutive doubles of row e and the other half a fixed quadratic
@@ -350,10 +568,10 @@ __device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, 
 // ds_read_b64 at n = 100.  Keys (i, j) and deltas are the same set; within a lane they still ascend with k.
 // MF: the group filter above; UR: steps per group -- both chosen by the caller from the register budget of the build (the filter costs
 // 16-28 B of scratch on the 64- / 80-VGPR builds, six steps per group 8-20 B on the single-slot 128-VGPR ones: those keep round 4's code)
-template <int SL, bool MF, int UR, class S, class TT>
+template <int SL, bool MF, int UR, class S, class TT, bool QT = false>
 __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, const double *Ef, int n,
                                                        int wave, int nwaves, int lane, double &bd, int &bk,
-                                                       const uint8_t *pos = nullptr) {
+                                                       const uint8_t *pos = nullptr, unsigned long long *qmask = nullptr) {
     const int RW = (n - 1 + kWave - 1) / kWave;              // row blocks of 64 rows
     const int per_rb = nwaves / RW;                          // waves sharing a row block, each a contiguous k range
     const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
@@ -377,6 +595,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     if (k0 >= k1) return;
     const int d0 = lane_tour_node(L, k0);
     double vd = s.dist_at(s.idx2(b, b2, d0, (d0 * (d0 - 1)) >> 1));       // D[t[k0], b]   (garbage, unused, where t[k0] == b)
+    double rowmin = __builtin_inf();                         // QT: minimum of every delta this lane forms (quiet rows, see scan_relocate_a2a_quiet)
     // U steps at a time: all wave-uniform operands, addresses and the U random distance reads are issued before the first
     // dependent add, so the LDS round trips of a group overlap (a step alone is a ~280-cycle dependent chain)
     auto group = [&](int k, int te, auto ucount, auto fast_addr) {        // te: the register slot holding positions k+1 .. k+U
@@ -399,7 +618,13 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
             dl[u] = delta + ve[u];                           // +D[b,e]
             vd = ve[u];
         }
-        if (!group_may_improve<MF>(dl, bd)) return;          // one exec-masked region per group instead of one per step
+        if constexpr (QT) {
+            const double gm = min_tree<0, U>(dl);            // (the group filter's minimum: one more v_min_f64 per group keeps the row's)
+            rowmin = min_f64_raw(rowmin, gm);
+            if (MF && GLS_LEAN_MINFILTER && U > 1 && !(gm < bd)) return;
+        } else {
+            if (!group_may_improve<MF>(dl, bd)) return;      // one exec-masked region per group instead of one per step
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = k + u;
@@ -428,6 +653,11 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
 #pragma unroll
         for (int q = 0; q < SL; ++q)                         // the slot that holds position n
             if (n / kWave == q) group(n - 1, L.t[q], U1{}, EXACT{});
+    }
+    if constexpr (QT) {
+        // rows some delta of which is below the quiet threshold stay active (the two garbage steps k in {i-1, i} included: a spurious
+        // bit costs one exact re-evaluation of the row by the next reduced scan, never a lost move)
+        if (row_ok && rowmin < kQuietThr) quiet_set(qmask, b);
     }
 }
 

@@ -125,6 +125,9 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             }
         }
     }
+    if constexpr (GLS_QUIET_ROWS && kCanPrune && GP == 2 && WPS <= 4) {
+        if (prune && tid == 0) quiet_reset(quiet_lds(ctl), quiet_count(ctl), lds_byte_addr(s.d));
+    }
     __syncthreads();
     if (prune) Lmax = unsortable(*lmax_slot(ctl));
     // pruned relocate scan: tour edges longer than Lcap (three mean edge lengths of the tour the descent starts from) are
@@ -134,13 +137,21 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     int *longk = reinterpret_cast<int *>(&ctl->red_d[0][3]);     // 16 ints: bytes 24 .. 87 of red_d
     int *nlong_slot = &ctl->red_k[1][0];
     (void)Lmax;
+    // quiet rows of the relocate scan (gls_descent_scans.h): the two-slot builds with neighbour lists on, i.e. 80 <= n <= 127 on the
+    // lean relocate scan; the first relocate scan of a descent is the full one and sets the bits
+    constexpr bool kQuietRows = GLS_QUIET_ROWS && kCanPrune && GP == 2 && WPS <= 4;
+    const bool quiet = kQuietRows && prune && nwaves >= 2 && (nwaves & (nwaves - 1)) == 0 && n <= GP * kWave - 1;
+    QuietLds *ql = quiet_lds(ctl);
+    int *qcount = quiet_count(ctl);
+    QuietLane qme{false};
+    bool have_bits = false;
     bool improved = true;
     while (improved) {                                               // algorithms.py:116
         improved = false;
 #pragma unroll 1
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
-            bool lean = false, pruned_scan = false;
+            bool lean = false, pruned_scan = false, quiet_scan = false;
             int xs = 0;          // evaluations this wavefront executes in a pruned scan (scalar; booked once per scan below)
             if constexpr (kCanPrune) {
                 int nlong = 0;
@@ -182,11 +193,34 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                     else         scan_relocate_a2a_lean_half<kHalfUnroll, S, TT>(s, t, Ef, n, lane, bd, bk);
                     lean = true;
                 }
+                if constexpr (kQuietRows) {
+                    if (!lean && op == 1 && quiet && have_bits) {
+#ifdef GLS_STAMPS
+                        const long long q0 = clock64();
+#endif
+                        const bool ok = scan_relocate_a2a_quiet<CNT, S, TT>(s, t, ppos, Ef, n, ql, qcount, qme, wave_u, nwaves, lane, bd, bk, xs);
+                        if (ok) {
+#ifdef GLS_STAMPS
+                            st.acc[20] += 1; st.acc[21] += clock64() - q0; st.acc[23] += __popcll(__ballot(qme.act));
+#endif
+                            lean = true; pruned_scan = true; quiet_scan = true;
+                        } else {                                     // pending list overflow (cannot happen): start over with a full scan
+                            have_bits = false; qme.act = false;
+                            __syncthreads();
+                            if (tid == 0) quiet_reset(ql, qcount, lds_byte_addr(s.d));
+                            __syncthreads();
+                        }
+                    }
+                }
                 if (!lean && nwaves >= (n - 1 + kWave - 1) / kWave && n <= GP * kWave - 1) {
                     // group filter on the 128-VGPR and wider builds, six steps per relocate group where two register slots leave room
                     constexpr bool kMF = WPS <= 4;
                     constexpr int kUR = (WPS <= 4 && GP == 2) ? GLS_LEAN_UNROLL_RELOCATE : GLS_LEAN_UNROLL;
                     if (op == 0) scan_two_opt_a2a_lean<GP, kMF, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
+                    else if (kQuietRows && quiet) {
+                        scan_relocate_a2a_lean<GP, kMF, kUR, S, TT, kQuietRows>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos, ql->words);
+                        have_bits = true;
+                    }
                     else         scan_relocate_a2a_lean<GP, kMF, kUR, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
                     lean = true;
                 }
@@ -205,6 +239,11 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             STAMP_END(8);    // a2a scan (this wave's share)
             if (!FI && nwaves > 1) block_reduce_best_lds(ctl, phase, tid, bd, bk);
             else block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
+            if constexpr (kQuietRows) {
+                // every wavefront has consumed the pending records and the rows to flag (two barriers ago at least): the wavefront that
+                // notes the moves (the last one) clears them, in program order before it notes this scan's own move
+                if (quiet_scan && wave_u == nwaves - 1 && lane == 0) { ql->words[0] = 0ull; ql->words[1] = 0ull; *qcount = 0; }
+            }
             STAMP_END(9);    // wave + workgroup arg-min (includes waiting for the slowest wave)
             STAMP_COUNT(11);
             if (tid == 0) evals += (op == 0) ? (long long)(n - 2) * (n - 3) / 2 : (long long)(n - 2) * (n - 2);
@@ -216,6 +255,10 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
                 apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos, prune ? ppos : nullptr, ctl, Lmax);
+                if constexpr (kQuietRows) {
+                    // the move's new tour edges go to the pending list of the next relocate scan's refresh (from the OLD tour)
+                    if (quiet && have_bits && wave_u == nwaves - 1) quiet_note_move(ql, qcount, lds_byte_addr(s.d), t, op, bk >> 16, bk & 0xffff, lane);
+                }
                 TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();
@@ -588,7 +631,8 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         long long *o2 = A.stamps + (size_t)A.B * 16 + (size_t)b * 16;
         if (TEAM) o2[wave] = st.acc[12];
         else if (wave == 0) { o2[0] = st.acc[16]; o2[1] = st.acc[17]; o2[2] = st.acc[18]; o2[3] = st.acc[19]; o2[4] = st.acc[15];      // pruned-scan counters
-                              o2[5] = st.acc[12]; o2[6] = st.acc[13]; o2[7] = st.acc[14]; }   // edge form: latch, divisions
+                              o2[5] = st.acc[12]; o2[6] = st.acc[13]; o2[7] = st.acc[14];     // edge form: latch, divisions
+                              o2[8] = st.acc[20]; o2[9] = st.acc[21]; o2[10] = st.acc[22]; o2[11] = st.acc[23]; }   // quiet rows
         o2[(size_t)A.B * 16 + wave] = st.acc[8];
         o2[(size_t)A.B * 32 + wave] = st.acc[9];
     }

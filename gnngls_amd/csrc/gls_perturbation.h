@@ -432,12 +432,6 @@ __device__ __forceinline__ void team_perturbation(const S &s, const double k, TT
 // dropped: evaluating several pending scans of a step at once, speculatively, in the reference's order of consumption (blocks
 // of two to four scans chosen by running acceptance estimates): bit-exact and 0.5-3 % slower than one scan at a time
 // (profiles/r05_experiments/).
-// -DGLS_ISA_MARKS (scripts/isa_critical_path.py): comment lines in the disassembly that delimit the regions of a penalty step
-#ifdef GLS_ISA_MARKS
-#define ISA_MARK(name) asm volatile("; GLSMARK " name)
-#else
-#define ISA_MARK(name) do {} while (0)
-#endif
 #ifndef GLS_EDGE_PREFETCH
 #define GLS_EDGE_PREFETCH 0           // edge form: issue the NEXT scan's loads under the current scan's wait, speculatively.  Measured
                                       // (profiles/r05_experiments/ab_edge_unrolled_and_prefetch.log, bit-exact): -1 % at TSP100 x 1024,

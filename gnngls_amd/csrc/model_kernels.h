@@ -26,9 +26,10 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
                            float *part_ms, hipStream_t st);
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
-                            const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, const float *fc_next,
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
                             float *ft_out, hipStream_t st);
-size_t ffn_packed_bytes();      // device scratch of the bf16x3 form of launch_ffn_fused (one layer's split weights)
+size_t ffn_packed_bytes();      // bytes of one layer's image for the bf16x3 form of launch_ffn_fused (split weights in fragment order)
+hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_next, void *packed, hipStream_t st);
 hipError_t launch_decision(const float *h, const float *w, const float *b, float *y, long M, hipStream_t st);
 
 }  // namespace gnngls

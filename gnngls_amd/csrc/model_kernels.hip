@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 // against the fp64 oracle the block's error is that of the fp32 kernel (tests/test_model_gpu.py, unchanged 1e-5 bar; the numpy
 // model of both paths: 4.5e-7 against 4.8e-7 of max|y|; three products, i.e. two pieces, would be 6.5e-6).  Inference only; the
 // training kernels above stay on the fp32 pipe.
-// The weights are split and laid out in fragment order once per launch by ffn_pack_bf16x3_kernel (786 KB per layer, L2-resident):
+// The weights are split and laid out in fragment order by ffn_pack_bf16x3_kernel, once per weight image (gnngls_regret_prepare; 786 KB per layer):
 //     W1p[c][kb][ht][p][lane][8]   = piece p of W1[128 c + 16 ht + (lane & 15)][32 kb + 8 (lane >> 4) + e]
 //     W2p[c][j][ot][p][lane][8]    = piece p of W2[16 ot + (lane & 15)][128 c + 32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
 // so that a stage's 24 KB are a flat copy into LDS and a wavefront's A fragment is one conflict-free ds_read_b128.  The k order of
@@ -1243,11 +1243,21 @@ static hipError_t launch_ffn_mode(const float *part, const float *part_ms, const
 
 size_t ffn_packed_bytes() { return kFfnPackedBytes; }
 
-// packed != nullptr (ffn_packed_bytes() of device scratch): the bf16x3 kernel; else the fp32 kernel.  With the bf16x3 kernel and
-// fc_next != nullptr the NEXT layer's ft = fc_next(hout) [M,128] is written to ft_out by the same launch (models.py:23 of layer l + 1)
+// One layer's feed-forward weights (and, if given, the NEXT layer's fc) split into bf16 pieces in fragment order: ffn_packed_bytes()
+// of device memory.  The image depends on the weights only -- gnngls_regret_prepare builds it once per weight image for all layers.
+hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_next, void *packed, hipStream_t st) {
+    unsigned char *pk = (unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ffn_pack_bf16x3_kernel, dim3(64), dim3(256), 0, st, W1, W2, pk);
+    if (fc_next) hipLaunchKernelGGL(ffn_pack_fc_bf16x3_kernel, dim3(8), dim3(256), 0, st, fc_next, pk_fc);
+    return hipGetLastError();
+}
+
+// packed != nullptr (a layer image made by launch_ffn_pack): the bf16x3 kernel; else the fp32 kernel.  With the bf16x3 kernel and
+// has_fc_next the NEXT layer's ft = fc_next(hout) [M,128] is written to ft_out by the same launch (models.py:23 of layer l + 1)
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
-                            const float *bn2_s, const float *bn2_b, float *hout, long M, void *packed, const float *fc_next,
+                            const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
                             float *ft_out, hipStream_t st) {
     if (packed) {
         const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
@@ -1255,12 +1265,9 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         (void)hipGetLastError();
-        unsigned char *pk = (unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
-        hipLaunchKernelGGL(ffn_pack_bf16x3_kernel, dim3(64), dim3(256), 0, st, W1, W2, pk);
-        if (fc_next) hipLaunchKernelGGL(ffn_pack_fc_bf16x3_kernel, dim3(8), dim3(256), 0, st, fc_next, pk_fc);
+        const unsigned char *pk = (const unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
         hipLaunchKernelGGL(ffn_fused_bf16x3_kernel, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
-                           bn1_s, bn1_b, (const unsigned char *)pk, b1, b2, bn2_s, bn2_b, hout, M,
-                           (const unsigned char *)(fc_next ? pk_fc : nullptr), ft_out);
+                           bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out);
         return hipGetLastError();
     }
     return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,

@@ -130,6 +130,7 @@ class EdgePropertyPredictionModel(nn.Module):
             *(AttentionLayer(embed_dim, n_heads, HIDDEN_DIM) for _ in range(n_heads)))
         self.decision_layer = nn.Linear(embed_dim, out_dim)
         self._packed = None
+        self._prepared = None       # device image of the split feed-forward weights (gnngls_regret_prepare), made with _packed
         self._workspace = None
 
     # -- weight image -----------------------------------------------------------------------------
@@ -299,9 +300,18 @@ def regret_forward(model, feat, B, n, max_workspace_bytes=48 << 30):
     L = _lib.load()
     dev = feat.device
     version = model._state_version()
+    n_layers = len(model.message_passing_layers)
     if model._packed is None or model._packed.device != dev or getattr(model, "_packed_version", None) != version:
         model._packed = model.pack_weights(dev)
         model._packed_version = version
+        # the weight-only part of the forward (bf16 pieces of the feed-forward / fc weights in MFMA fragment order), once per
+        # weight image instead of once per call (test.py:43-54 loads the checkpoint once, test.py:72-77 calls per instance)
+        if not hasattr(L, "gnngls_regret_forward_prepared"):                  # (an ABI-3 build named by GNNGLS_HIP_SO: A/B runs)
+            model._prepared = None
+        else:
+            model._prepared = torch.empty(int(L.gnngls_regret_prepared_bytes(n_layers)), dtype=torch.uint8, device=dev)
+            _lib.check(L.gnngls_regret_prepare(_lib.ptr(model._packed), model.in_dim, n_layers, _lib.ptr(model._prepared),
+                                               ctypes.c_int64(model._prepared.numel()), _lib.current_stream()), "regret_prepare")
     N = n * (n - 1) // 2
     need = int(L.gnngls_regret_forward_workspace_bytes(B, n))
     ws_bytes = min(need, max(int(L.gnngls_regret_forward_workspace_bytes(1, n)), max_workspace_bytes))
@@ -311,9 +321,14 @@ def regret_forward(model, feat, B, n, max_workspace_bytes=48 << 30):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         model._workspace = ws
     y = torch.empty((B, N), dtype=torch.float32, device=dev)
-    _lib.check(L.gnngls_regret_forward(_lib.ptr(feat), _lib.ptr(model._packed), B, n, model.in_dim,
-                                       len(model.message_passing_layers), _lib.ptr(y), _lib.ptr(ws),
-                                       ctypes.c_int64(ws.numel()), _lib.current_stream()), "regret_forward")
+    if model._prepared is None:
+        _lib.check(L.gnngls_regret_forward(_lib.ptr(feat), _lib.ptr(model._packed), B, n, model.in_dim, n_layers, _lib.ptr(y),
+                                           _lib.ptr(ws), ctypes.c_int64(ws.numel()), _lib.current_stream()), "regret_forward")
+        return y
+    _lib.check(L.gnngls_regret_forward_prepared(_lib.ptr(feat), _lib.ptr(model._packed), _lib.ptr(model._prepared),
+                                                ctypes.c_int64(model._prepared.numel()), B, n, model.in_dim, n_layers,
+                                                _lib.ptr(y), _lib.ptr(ws), ctypes.c_int64(ws.numel()), _lib.current_stream()),
+               "regret_forward")
     return y
 
 

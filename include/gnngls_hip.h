@@ -174,6 +174,19 @@ int64_t gnngls_regret_forward_workspace_bytes(int B, int n);
 int gnngls_regret_forward(const float *feat, const float *weights, int B, int n, int in_dim, int n_layers,
                           float *y_out, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ABI v4 -- the same forward with the weight-only work hoisted out of it (test.py:43-54 loads a checkpoint ONCE and then
+ * calls the model per instance, test.py:72-77): the feed-forward block (models.py:26-36) and the folded GATConv fc (models.py:23)
+ * run on the bf16 matrix pipe from three bf16 pieces per fp32 weight in MFMA fragment order; that image depends on the weights
+ * only.  gnngls_regret_prepare writes it for all layers into `prepared` (caller-owned device memory of
+ * gnngls_regret_prepared_bytes(n_layers) bytes, valid until the weights change); gnngls_regret_forward_prepared is
+ * gnngls_regret_forward reading it (prepared == NULL: the feed-forward block stays on the fp32 matrix pipe).
+ * gnngls_regret_forward itself prepares into stream-ordered scratch on every call (2 launches per layer more). */
+int64_t gnngls_regret_prepared_bytes(int n_layers);
+int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *prepared, int64_t prepared_bytes, void *stream);
+int gnngls_regret_forward_prepared(const float *feat, const float *weights, const void *prepared, int64_t prepared_bytes,
+                                   int B, int n, int in_dim, int n_layers,
+                                   float *y_out, void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- N4: one training step of the same model (scripts/train.py:20-32) -------------------------------------------
  * model.train(); y_pred = model(batch, x); loss = criterion(y_pred, y); loss.backward() for a dgl.batch of B line graphs
  * of K_n (train.py:118-121): BatchNorm1d uses the statistics of all B*N rows (models.py:27,35), GATConv is

@@ -292,6 +292,47 @@ def synthetic_state_dict(model, seed):
     return out
 
 
+def trained_like_state_dict(model, seed, fc_gain=3.0, running_stats=None, calib_n=24):
+    """A synthetic checkpoint with the weight scales a TRAINED model shows rather than those of the initialisation: BatchNorm
+    gamma in [0.5, 4] and beta ~ N(0, 0.5), the GATConv linear map at `fc_gain` times its initial gain (larger attention logits),
+    feed-forward weights at their default initialisation -- and, as in a trained model, the
+    BatchNorm running statistics ARE the statistics of the activations (one calibration pass over a K_calib_n line graph with
+    momentum 1), so the activations stay normalised from layer to layer instead of growing with gamma^16.
+    running_stats: {key: tensor} of running_mean / running_var from an earlier calibration (the forward error fixtures store them:
+    bit-identical checkpoints on every machine); None = calibrate here.  Returns (state_dict, running_stats).
+    Such networks are ILL-CONDITIONED in fp32: a plain fp32 evaluation of the reference's own graph is 3 x (fc_gain 1) to 10-250 x
+    (fc_gain 3) the 1e-5 parity bar away from the fp64 value at n = 50 -- the fixtures record that error next to the expected outputs."""
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if ".feed_forward.0.weight" in k or ".feed_forward.2.weight" in k:
+            out[k] = 0.5 + 3.5 * torch.rand(v.shape, generator=g)          # gamma in [0.5, 4]
+        elif ".feed_forward.0.bias" in k or ".feed_forward.2.bias" in k:
+            out[k] = 0.5 * torch.randn(v.shape, generator=g)
+        elif k.endswith("fc.weight"):
+            out[k] = fc_gain * v.clone()
+        else:
+            out[k] = v.clone()
+    if running_stats is None:
+        import copy
+        m = copy.deepcopy(model)
+        m.load_state_dict(out)
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm1d):
+                mod.momentum = 1.0
+        m.train()
+        N = calib_n * (calib_n - 1) // 2
+        x = torch.rand((N, 1), generator=g)
+        with torch.no_grad():
+            m(line_graph_arcs_closed_form(calib_n), x)
+        cal = m.state_dict()
+        running_stats = {k: cal[k].clone() for k in cal if k.endswith("running_mean") or k.endswith("running_var")}
+    for k, v in running_stats.items():
+        out[k] = v.clone().to(out[k].dtype)
+    return out, running_stats
+
+
 def train_step_reference(model, G, x, target, criterion=None):
     """One optimisation step's forward/backward exactly as train.py:20-32 runs it (model.train(); y_pred = model(batch, x);
     loss = criterion(y_pred, y); loss.backward()), on CPU through torch autograd.

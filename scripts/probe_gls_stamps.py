@@ -62,6 +62,11 @@ simd = [((raw[:, 7] >> (8 * w)) & 0xff) - 1 for w in range(4)]
 import collections
 print("SIMD of waves 0..3 (count of instances):", collections.Counter(zip(*[x.tolist() for x in simd])).most_common(6))
 print(f"moves/iter {r.trace_len.double().mean().item() / it:.1f}, evals/iter {r.evals.double().mean().item() / it:.0f}")
+if per_wave[8] > 0:
+    full = max(sc / 2 - per_wave[8], 1)
+    print(f"quiet rows (wavefront 0): reduced relocate scans / iter {per_wave[8] / it:.2f}, cycles per refresh + reduced scan {per_wave[9] / per_wave[8]:.0f}, "
+          f"flagged rows of the wavefront after a reduced scan {per_wave[11] / per_wave[8]:.1f}; full relocate scans / iter {full / it:.2f}, "
+          f"cycles each {(per_wave[4] - per_wave[9]) / full:.0f}")
 if n < 128 and per_wave[4] > 0:
     print(f"descent scans of wavefront 0: relocate {per_wave[4] / max(sc / 2, 1):.0f} cycles per scan, 2-opt {(st[8] - per_wave[4]) / max(sc / 2, 1):.0f}")
 if int(os.environ.get("TEAM", "-1")) == 0 and per_wave[:4].sum() > 0:

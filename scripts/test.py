@@ -150,16 +150,48 @@ def solve_block(names, test_set, model, scalers, args, chunk, budget='per_instan
     return records, gaps
 
 
-def gather_records(records, world, rank):
+def records_to_array(records, n_instances, width):
+    """The records of this rank's instances (in order: a start row, then progress rows) as ONE fixed-width fp64 array
+    [n_instances, 3 + 2 width]: opt_cost, start time, number of progress rows, their times, their costs (NaN padded).
+    width = --full_trace + IMP_CAP: a function of the command line alone, so every rank knows every rank's shape."""
+    out = np.full((n_instances, 3 + 2 * width), np.nan)
+    k = -1
+    for r in records:
+        if 'cost' not in r:                                                   # start row of the next instance (test.py:65-68)
+            k += 1
+            out[k, 0], out[k, 1], out[k, 2] = r['opt_cost'], r['time'], 0
+        else:
+            m = int(out[k, 2])
+            out[k, 3 + m], out[k, 3 + width + m] = r['time'], r['cost']
+            out[k, 2] = m + 1
+    assert k == n_instances - 1
+    return out
+
+
+def array_to_records(arr, names, width):
+    records = []
+    for row, name in zip(arr, names):
+        opt = float(row[0])
+        records.append({'instance': name, 'time': float(row[1]), 'opt_cost': opt})
+        m = int(row[2])
+        records += [{'instance': name, 'opt_cost': opt, 'time': float(t), 'cost': float(c)}
+                    for t, c in zip(row[3:3 + m], row[3 + width:3 + width + m])]
+    return records
+
+
+def gather_records(records, world, rank, names_all, n_local, width):
+    """The one exchange of the run: a tensor `gather` of fixed-width record arrays (gnngls_amd.parallel.gather_results: shard
+    sizes are a function of (total, world), no size exchange, no pickling through the collective)."""
     if not dist.is_initialized():
         return records
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object(records, parts, dst=0)                                 # the one exchange of the run
+    local = torch.from_numpy(records_to_array(records, n_local, width))
+    on_gpu = dist.get_backend() == 'nccl'                                     # RCCL moves device memory
+    g = parallel.gather_results(local.cuda() if on_gpu else local, parallel.shard_sizes(len(names_all), world))
     dist.barrier()
     dist.destroy_process_group()
     if rank != 0:
         return None
-    return [row for part in parts for row in part]
+    return array_to_records(g.cpu().numpy(), names_all, width)
 
 
 def write_progress(records, run_dir):
@@ -197,7 +229,7 @@ def main():
             pbar.set_postfix({'Avg Gap': '{:.4f}'.format(np.mean(gaps))})
             pbar.update(len(names))
 
-    records = gather_records(records, world, rank)
+    records = gather_records(records, world, rank, test_set.instances, len(mine), args.full_trace + IMP_CAP + 1)
     if records is not None:
         write_progress(records, args.run_dir)
 

@@ -131,33 +131,35 @@ def test_search_progress_record_helpers():
 
 
 def test_search_roofline_object_is_self_consistent():
+    """Round 6: the primary fraction is SURVEY 8(d)'s executed-LDS figure, measured in the run; counters and the critical path are
+    side records and there is no derived `bound` label any more."""
     b = bench_module()
-    traffic = {"valu_busy_frac": 0.6, "lds_busy_frac": 0.7, "clock_ghz": 2.0, "hbm_bytes_per_instance_second": 10.0,
+    traffic = {"valu_busy_frac": 0.6, "lds_busy_frac": 0.7, "clock_ghz": 2.0, "hbm_bytes_per_instance_second": 10.0, "wave_wait_frac": 0.65,
                "workload": {"n": 100, "instances": 1024, "guide": "model"}}
     r = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, traffic, {"n": 100, "instances": 1024, "guide": "model"})
-    assert r["frac"] == 0.6 and r["peak"] == 2048.0 and abs(r["achieved"] - 0.6 * 2048.0) < 1e-9      # no cycle records: the committed counter
-    assert "committed PMC pass" in r["frac_source"] and r["bound"] == "lds_issue" and r["critical_path"] is None
-    cyc = {"kernel_cycles": np.array([2e9, 2e9]), "pert_cycles": np.array([8e8, 8e8]), "steps": np.array([1.6e5, 1.6e5]),
-           "ticks": np.array([1e8, 1e8]), "outer_iters": np.array([9000., 9000.])}
-    lat = dict(traffic, valu_busy_frac=0.55, lds_busy_frac=0.3, wave_wait_frac=0.65)
-    rc = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, lat, {"n": 100, "instances": 1024, "guide": "model"}, cyc)
-    cp = rc["critical_path"]
-    assert rc["bound"] == "latency" and cp["measured_cycles"] == 5000.0 and abs(cp["clock_ghz"] - 2.0) < 1e-12
-    assert abs(rc["frac"] - cp["floor_cycles"] / 5000.0) < 1e-12 and abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-12
-    assert abs(cp["share_of_kernel_cycles"] - 0.4) < 1e-12 and abs(cp["penalty_steps_per_outer_iteration"] - 160000 / 9000) < 1e-9
     # 4 launches of 1 s over 2 steps -> 2 launches per step; the evaluation counts are one step's
     assert abs(r["reference_equivalent_evals_per_s"] - 4e9) < 1 and abs(r["executed_evals_per_s"] - 1e9) < 1 and r["prune_ratio"] == 0.25
-    assert r["binding_resource"]["name"] == "lds_issue" and r["binding_resource"]["second"] == "valu"    # sorted, not hard-coded
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == 150000.0 and "SURVEY 8(d)" in r["frac_definition"]
+    assert abs(r["achieved"] - 1e9 * r["lds_bytes_per_eval"] / 1e9) < 1e-9 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-15
+    assert abs(r["reference_equivalent_frac"] - 4.0 * r["frac"]) < 1e-12 and r["critical_path"] is None
+    assert [p["pipe"] for p in r["busiest_pipes"]] == ["lds", "valu"] and r["wave_wait_frac"] == 0.65      # sorted, not hard-coded; no label
     assert r["pmc_matches_workload"] and r["traffic"] == 10.0 * 1024 * 1.0
-    # counters of another workload: kept for reference, no fraction derived from them
+    cyc = {"kernel_cycles": np.array([2e9, 2e9]), "pert_cycles": np.array([8e8, 8e8]), "steps": np.array([1.6e5, 1.6e5]),
+           "ticks": np.array([1e8, 1e8]), "outer_iters": np.array([9000., 9000.])}
+    rc = b.search_roofline(100, 2, 4000.0, 4, 8e9, 0.25, 1024, traffic, {"n": 100, "instances": 1024, "guide": "model"}, cyc)
+    cp = rc["critical_path"]
+    assert rc["frac"] == r["frac"] and cp["measured_cycles"] == 5000.0 and abs(cp["clock_ghz"] - 2.0) < 1e-12      # a side record only
+    assert abs(cp["frac"] - cp["floor_cycles"] / 5000.0) < 1e-12
+    assert abs(cp["share_of_kernel_cycles"] - 0.4) < 1e-12 and abs(cp["penalty_steps_per_outer_iteration"] - 160000 / 9000) < 1e-9
+    # counters of another workload: no pipes, no traffic derived from them; the fraction is this run's own and stays
     rm = b.search_roofline(200, 1, 1000.0, 1, 1e9, 0.03, 256, traffic, {"n": 200, "instances": 256, "guide": "model"})
-    assert rm["frac"] is None and rm["traffic"] is None and rm["binding_resource"]["name"] is None and not rm["pmc_matches_workload"]
-    assert rm["pmc"]["valu_busy_frac"] == 0.6
+    assert rm["frac"] is not None and rm["traffic"] is None and rm["busiest_pipes"] is None and rm["pmc"] is None and not rm["pmc_matches_workload"]
     r2 = b.search_roofline(50, 1, 1000.0, 1, 1e9, 1.0, 128, {}, {"n": 50, "instances": 128, "guide": "model"})
-    assert r2["frac"] is None and r2["binding_resource"]["name"] is None and not r2["pmc_matches_workload"] and r2["traffic"] is None
-    assert r2["prune_ratio"] == 1.0 and r2["lds_executed"]["frac"] == r2["reference_equivalent_frac"]
-    r3 = b.search_roofline(100, 1, 1000.0, 1, 1e9, None, 64, {}, {"n": 100, "instances": 64, "guide": "model"})   # no counting instantiation
-    assert r3["prune_ratio"] is None and r3["executed_evals_per_s"] is None and r3["lds_executed"] is None
+    assert r2["prune_ratio"] == 1.0 and abs(r2["frac"] - r2["reference_equivalent_frac"]) < 1e-15 and r2["traffic"] is None
+    r3 = b.search_roofline(100, 1, 1000.0, 1, 1e9, None, 64, {}, {"n": 100, "instances": 64, "guide": "model"})   # pruning, but no counting instantiation
+    assert r3["prune_ratio"] is None and r3["executed_evals_per_s"] is None and r3["frac"] is None and r3["achieved"] is None
+    r4 = b.search_roofline(50, 1, 1000.0, 1, 1e9, None, 64, {}, {"n": 50, "instances": 64, "guide": "model"})     # below n = 80 nothing prunes
+    assert r4["prune_ratio"] is None and abs(r4["frac"] - r4["reference_equivalent_frac"]) < 1e-15
 
 
 def test_instance_blocks_and_best_known_file(tmp_path):

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_host_queries(lib):
-    assert lib.gnngls_abi_version() == 3
+    assert lib.gnngls_abi_version() == 4
     assert lib.gnngls_gls_resident_capacity(2) == 0
     caps = [lib.gnngls_gls_resident_capacity(n) for n in (20, 50, 100, 150)]
     assert all(c > 0 for c in caps) and caps == sorted(caps, reverse=True)

@@ -1,7 +1,8 @@
 """GPU parity tests of the edge-regret GNN forward (HIP, through the C ABI) against golden outputs
 captured from the reference's models.py and against the CPU oracle (oracle/model_oracle.py).
-Tolerance: 1e-5 relative on the regret predictions (BASELINE.json north_star), with an absolute floor
-of 1e-5 * max|y| for outputs near zero."""
+Tolerance: |y - ref| <= 1e-5 * max(|ref|, output scale) with output scale = max|ref| of the instance -- 1e-5
+relative on the regret predictions (BASELINE.json north_star) with the absolute floor outputs near zero need.  (Rounds 1-5
+asserted the looser sum 1e-5 |ref| + 1e-5 max|ref|, up to twice this bound at the top of the range.)"""
 import os
 
 import numpy as np
@@ -15,11 +16,16 @@ RTOL = 1e-5
 ESCAPES = []      # (n, instance, max err, fp32 reference's own err) of cases that passed on the small-graph clause only
 
 
+def regret_bound(ref):
+    """1e-5 * max(|ref|, output scale), output scale = max|ref|"""
+    ref = np.abs(np.asarray(ref, dtype=np.float64))
+    return RTOL * np.maximum(ref, ref.max())
+
+
 def assert_regret_close(y, ref):
     y, ref = np.asarray(y, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
-    floor = RTOL * np.abs(ref).max()
     err = np.abs(y - ref)
-    bound = RTOL * np.abs(ref) + floor
+    bound = regret_bound(ref)
     assert (err <= bound).all(), f"max err {err.max():.3e}, worst ratio {(err / bound).max():.2f}"
 
 
@@ -56,7 +62,7 @@ def test_forward_golden(n):
 def test_forward_batch_vs_oracle(n, B):
     """HIP fp32 forward vs the CPU oracle on seeded random batches.
 
-    The bar is 1e-5 relative (with the 1e-5*max|y| floor) against the oracle evaluated in fp64 --
+    The bar is 1e-5 * max(|ref|, max|ref|) against the oracle evaluated in fp64 --
     the exact value both fp32 implementations approximate.  A plain fp32 evaluation of the
     reference's own graph (the fp32 oracle, different summation order) is itself only within
     3e-6 .. 1.3e-5 of that value (worst for tiny ill-conditioned graphs such as n=4 where the
@@ -80,7 +86,7 @@ def test_forward_batch_vs_oracle(n, B):
             ref64 = oracle64(G1, xb.double()).numpy().reshape(-1)
             ref32 = oracle(G1, xb).numpy().reshape(-1).astype(np.float64)
             err = np.abs(y[b] - ref64)
-            bound = RTOL * np.abs(ref64) + RTOL * np.abs(ref64).max()
+            bound = regret_bound(ref64)
             ref_err = np.abs(ref32 - ref64).max()
             strict_ok = bool((err <= bound).all())
             if not strict_ok and n < 20:
@@ -91,7 +97,7 @@ def test_forward_batch_vs_oracle(n, B):
             # a usable yardstick (its own rounding error well inside the bar; not so for some tiny ill-conditioned graphs)
             if n >= 5 and ref_err <= 0.5 * RTOL * np.abs(ref64).max():
                 err32 = np.abs(y[b] - ref32)
-                assert (err32 <= RTOL * np.abs(ref32) + RTOL * np.abs(ref32).max()).all(), \
+                assert (err32 <= regret_bound(ref32)).all(), \
                     f"n={n} b={b}: max |hip - fp32 reference| {err32.max():.3e}"
 
 
@@ -99,7 +105,7 @@ def test_forward_n200_vs_oracle():
     """BASELINE configs[4] size: ONE TSP200 instance (19,900 line-graph nodes, 7.9 million arcs) through the HIP forward
     -- the head-split gat_rows_kernel<4> (two workgroups per TSP row, 115 KB tiles) -- against the oracle evaluated in
     fp64 (arcs from the closed-form rule, aggregation per destination range: tests/test_model_oracle.py pins both to the
-    networkx line graph), 1e-5 relative with the 1e-5 * max|y| floor, no alternative clause."""
+    networkx line graph), 1e-5 * max(|ref|, max|ref|), no alternative clause."""
     import copy
     from gnngls_amd.models import LineGraph
     from oracle import model_oracle as mo
@@ -134,6 +140,68 @@ def test_forward_headline_batch_instances_alone_and_vs_oracle():
             assert torch.equal(alone, y[b]), b
         ref = copy.deepcopy(oracle).double()(mo.line_graph_arcs_closed_form(n), x[511 * N:512 * N].cpu().double())
     assert_regret_close(y[511].cpu().numpy(), ref.numpy().reshape(-1))
+
+
+def test_forward_headline_batch_eight_instances_vs_oracle_fixtures():
+    """The 1,024-instance TSP100 call again, with the rows of the 16 fixture instances (tests/golden/forward_error_n100.npz: fp64
+    oracle outputs made on the build container's CPUs) spread over the batch -- instances 0, 64, 129, ... -- for the two checkpoints
+    at initialisation scale: every one of their 8 instances within the bar wherever it sits in the launch grid."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_forward_error_fixtures as F
+    from gnngls_amd import models as M
+    fx = np.load(os.path.join(GOLD, "forward_error_n100.npz"))
+    n, B = 100, 1024
+    N = n * (n - 1) // 2
+    per = int(fx["per_checkpoint"])
+    for c, (ms, ss, kind) in enumerate(fx["checkpoints"].tolist()):
+        if kind != 0:
+            continue
+        _, sd, _ = F.checkpoint(ms, ss, kind)
+        model = M.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+        model.load_state_dict(sd)
+        model.eval().to("cuda")
+        x = torch.from_numpy(np.random.default_rng(77 + c).random((B * N, 1)).astype(np.float32))
+        slots = [(129 * k + 64 * c) % B for k in range(per)]
+        for k, b in enumerate(slots):
+            x[b * N:(b + 1) * N] = torch.from_numpy(F.features(n, c, k))
+        with torch.no_grad():
+            y = M.regret_forward(model, x.cuda(), B, n).reshape(B, N).cpu().numpy()
+        for k, b in enumerate(slots):
+            assert_regret_close(y[b], fx["ref64"][c, k])
+
+
+@pytest.mark.parametrize("n", [100, 200])
+def test_forward_error_fixtures(n):
+    """The sizes the bench runs, 16 instances each over four seeded checkpoints (tests/golden/make_forward_error_fixtures.py): two
+    at initialisation scale -- the bar is asserted as it stands -- and two with trained-like weight scales (BatchNorm gamma up to 4,
+    calibrated running statistics, GATConv fc at 3 x / 1 x its initial gain).  The latter are ill-conditioned in fp32: the fixtures
+    record that a plain fp32 evaluation of the reference's own graph is 1-35 x the bar away from the fp64 value there, so what is
+    asserted for them is that the HIP forward is no further from the exact value than 3 x that evaluation (the clause the tiny
+    graphs of test_forward_batch_vs_oracle have); scripts/forward_error_fixtures.py prints the table
+    (profiles/r06_forward_error_fixtures.txt)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import make_forward_error_fixtures as F
+    from gnngls_amd import models as M
+    fx = np.load(os.path.join(GOLD, f"forward_error_n{n}.npz"))
+    per = int(fx["per_checkpoint"])
+    for c, (ms, ss, kind) in enumerate(fx["checkpoints"].tolist()):
+        stats = {k.split(":", 1)[1]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(f"stats{c}:")} or None
+        _, sd, _ = F.checkpoint(ms, ss, kind, stats)
+        model = M.EdgePropertyPredictionModel(1, 128, 1, 3, n_heads=8)
+        model.load_state_dict(sd)
+        model.eval().to("cuda")
+        x = torch.from_numpy(np.concatenate([F.features(n, c, k) for k in range(per)])).cuda()
+        with torch.no_grad():
+            y = M.regret_forward(model, x, per, n).cpu().numpy().astype(np.float64)
+        for k in range(per):
+            ref, own = fx["ref64"][c, k], float(fx["fp32_eval_max_err"][c, k])
+            err = np.abs(y[k] - ref)
+            if kind == 0:
+                assert (err <= regret_bound(ref)).all(), (n, c, k, err.max() / (RTOL * np.abs(ref).max()))
+            else:
+                assert (err <= regret_bound(ref)).all() or err.max() <= 3.0 * own, (n, c, k, err.max(), own)
 
 
 @pytest.mark.parametrize("in_dim,n,B", [(3, 12, 2), (2, 33, 1)])
@@ -234,7 +302,7 @@ def test_forward_with_saturated_attention(scale):
         ref32 = oracle.eval()(G, x).double().numpy().reshape(-1)
     assert np.isfinite(y).all()
     err, own = np.abs(y - ref64), np.abs(ref32 - ref64).max()
-    assert (err <= RTOL * np.abs(ref64) + RTOL * np.abs(ref64).max()).all() or err.max() <= 3.0 * own, (err.max(), own)
+    assert (err <= regret_bound(ref64)).all() or err.max() <= 3.0 * own, (err.max(), own)
 
 
 def test_feed_forward_block_paths_agree_and_fc_rides_in_the_block():

@@ -65,3 +65,54 @@ def test_gather_results_single_process_is_identity():
     from gnngls_amd import parallel
     x = torch.arange(6.).reshape(3, 2)
     assert parallel.gather_results(x) is x
+
+
+def _cli_worker(rank, world, port, total, q):
+    """scripts/test.py's exchange: fixed-width record arrays through ONE tensor gather (no gather_object)."""
+    import importlib.util
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gnngls_cli_gather", os.path.join(root, "scripts", "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    from gnngls_amd import parallel
+    names = [f"i{k}.pkl" for k in range(total)]
+    lo, hi = parallel.shard_range(total, world, rank)
+    records = []
+    for k in range(lo, hi):                                    # instance k: a start row and k % 3 + 1 progress rows
+        records.append({"instance": names[k], "time": 100.0 + k, "opt_cost": 2.0 + k})
+        records += [{"instance": names[k], "opt_cost": 2.0 + k, "time": 100.0 + k + 0.25 * (r + 1), "cost": 9.0 - r + k}
+                    for r in range(k % 3 + 1)]
+    calls = []
+    real = {name: getattr(dist, name) for name in ("gather", "gather_object", "all_gather", "all_gather_object")}
+    for name, f in real.items():
+        setattr(dist, name, lambda *a, _f=f, _n=name, **kw: (calls.append(_n), _f(*a, **kw))[1])
+    out = cli.gather_records(records, world, rank, names, hi - lo, 4)
+    for name, f in real.items():
+        setattr(dist, name, f)
+    assert calls == ["gather"]
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out is None
+
+
+def test_cli_records_gather_gloo_world2_uneven():
+    world, total = 2, 5            # 3 + 2 instances
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    expect = []
+    for k in range(total):
+        expect.append({"instance": f"i{k}.pkl", "time": 100.0 + k, "opt_cost": 2.0 + k})
+        expect += [{"instance": f"i{k}.pkl", "opt_cost": 2.0 + k, "time": 100.0 + k + 0.25 * (r + 1), "cost": 9.0 - r + k}
+                   for r in range(k % 3 + 1)]
+    assert out == expect
