@@ -51,6 +51,7 @@ GAP_GRID_S = (0.1, 0.3, 1.0, 3.0)   # search seconds at which the gap-versus-bud
 IMP_CAP = 256                    # improvement-trace entries kept per instance (a 10 s TSP100 search improves its best a few dozen times)
 ISO_ROUNDS = 10                  # device loads that share ONE time limit in the iso-quality pass
 ISO_FRONTIER = (1.0, 3.0, 10.0)  # ... at the full limit, a third and a tenth of it: per load what 10 / 30 / 100 loads get in the full one
+ISO_GAP_TARGETS = (0.1, 0.03, 0.01)   # mean gaps (percent) at which throughput is reported: instances/s at FIXED quality
 COUNT_PASS_S = 2.0               # length of the untimed pass that measures executed / reference-equivalent evaluations
 
 
@@ -166,6 +167,20 @@ def gap_curve(sums, grid, pre_search_s):
              "at_best_known_pct": float(100.0 * ab / max(cnt, 1.0))} for t, (sg, ab, cnt) in zip(grid, sums)]
 
 
+def time_to_gap(imp_cost, imp_time, imp_len, init_cost, best_known, targets, t_max):
+    """Search seconds after which the MEAN gap of these instances is first <= each target (percent), from their improvement
+    traces (best tour length known at t = cummin over the progress rows, test.py:97-117), on a 2 % geometric grid; None where the
+    record never gets there within t_max."""
+    grid = np.geomspace(1e-3, max(t_max, 2e-3), int(np.ceil(np.log(max(t_max, 2e-3) / 1e-3) / np.log(1.02))) + 1)
+    bt, _ = best_at_times(imp_cost, imp_time, imp_len, init_cost, grid)
+    gaps = ((bt / np.asarray(best_known)[:, None] - 1.0) * 100.0).mean(axis=0)
+    out = []
+    for g in targets:
+        ok = np.nonzero(gaps <= g)[0]
+        out.append(float(grid[ok[0]]) if len(ok) else None)
+    return out
+
+
 def physical_cores():
     """(physical cores, hardware threads) of the host from /proc/cpuinfo (unique (physical id, core id) pairs)."""
     pairs, threads, phys = set(), 0, None
@@ -186,11 +201,19 @@ def physical_cores():
 def load_critical_path(n):
     """Committed dependent-chain / issue model of one penalty step of the search kernel's serial perturbation phase for TSP<n>
     (profiles/r05_isa/critical_path.json, made by scripts/isa_critical_path.py from the disassembly of the shipped instantiation
-    and the measured per-instruction constants of scripts/isa_probe/latency_probe.hip); None if there is none for this size."""
+    and the measured per-instruction constants of scripts/isa_probe/latency_probe.hip), with the round-6 issue model of the descent
+    scans under "descent" if profiles/r06_isa/descent_model.json has this size; None if there is no model for this size."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r05_isa", "critical_path.json"))).get(f"tsp{n}")
+        cp = json.load(open(os.path.join(ROOT, "profiles", "r05_isa", "critical_path.json"))).get(f"tsp{n}")
     except (OSError, ValueError):
-        return None
+        cp = None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_isa", "descent_model.json"))).get(f"tsp{n}")
+    except (OSError, ValueError):
+        d = None
+    if d is not None:
+        cp = dict(cp or {}, descent=d)
+    return cp
 
 
 def critical_path(n, cyc):
@@ -213,10 +236,39 @@ def critical_path(n, cyc):
            "share_of_kernel_cycles": float(pert / kern), "clock_ghz": float(kern / (cyc["ticks"].sum() * 1e-8) / 1e9),
            "measured_how": "untimed %g s pass of this workload on the counting instantiation: s_memtime around every perturbation "
                            "phase / penalty steps counted by the kernel, all instances" % COUNT_PASS_S}
-    if cp:
+    if cp and "chain_floor_cycles_per_step" in cp:
         out.update({"floor_cycles": cp["chain_floor_cycles_per_step"], "frac": float(cp["chain_floor_cycles_per_step"] / measured),
                     "issue_model_cycles": cp["issue_model_cycles_per_step"], "measured_over_issue_model": float(measured / cp["issue_model_cycles_per_step"]),
                     "floor_source": cp.get("source")})
+    out["coverage_of_kernel_cycles"] = float(pert / kern)
+    if "descent_cycles" in cyc:
+        # round 6: the other phase of an outer iteration, the descent (algorithms.py:188 -> 111-132), from the same counting pass:
+        # shader cycles of wavefront 0 in the all-to-all scans of each kind, in the workgroup arg-min (incl. waiting for the slowest
+        # wavefront) and in move application + barrier, against the issue model of profiles/r06_isa/descent_model.json: executed
+        # instructions of ONE wavefront's share of a scan x the cycles an instruction costs a wavefront that shares its SIMD with
+        # three others (the model's constant, stated there)
+        desc = cyc["descent_cycles"].sum()
+        model = (cp or {}).get("descent", {})
+        kinds = ("two_opt_a2a (pruned scan from n = 80)", "relocate_a2a, every row (first relocate scan of a descent)",
+                 "relocate_a2a, flagged rows only (quiet rows, 80 <= n <= 127)")
+        keys = ("two_opt", "relocate_full", "relocate_flagged")
+        scans = {}
+        for q, (name, key) in enumerate(zip(kinds, keys)):
+            cnt, cy = cyc["scans"][q].sum(), cyc["scan_cycles"][q].sum()
+            if cnt <= 0:
+                continue
+            m = model.get(key, {}).get("issue_model_cycles")
+            scans[key] = {"what": name, "per_outer_iteration": float(cnt / iters), "measured_cycles": float(cy / cnt),
+                          "instructions_executed": model.get(key, {}).get("instructions_executed"),
+                          "issue_model_cycles": m, "measured_over_issue_model": float(cy / cnt / m) if m else None}
+        nscans = sum(c.sum() for c in cyc["scans"])
+        out["descent"] = {"cycles_per_outer_iteration": float(desc / iters), "share_of_kernel_cycles": float(desc / kern),
+                          "scans": scans,
+                          "argmin_and_wait_cycles_per_scan": float(cyc["argmin_cycles"].sum() / max(nscans, 1)),
+                          "apply_and_barrier_cycles_per_move": float(cyc["apply_cycles"].sum() / max(cyc["moves"].sum(), 1)),
+                          "moves_per_outer_iteration": float(cyc["moves"].sum() / iters),
+                          "model_source": model.get("source"), "cycles_per_instruction_of_the_model": model.get("cycles_per_instruction")}
+        out["coverage_of_kernel_cycles"] = float((pert + desc) / kern)
     return out
 
 
@@ -350,7 +402,7 @@ def load_traffic():
     """HBM traffic from the committed PMC passes (profiles/traffic_r0*.json, newest first: FETCH_SIZE/WRITE_SIZE collected
     and corrected as MI355X_MICROARCH.md prescribes)."""
     merged = {}
-    for name in ("traffic_r01.json", "traffic_r02.json", "traffic_r03.json", "traffic_r04.json", "traffic_r05.json"):
+    for name in ("traffic_r01.json", "traffic_r02.json", "traffic_r03.json", "traffic_r04.json", "traffic_r05.json", "traffic_r06.json"):
         try:
             merged.update(json.load(open(os.path.join(ROOT, "profiles", name))))
         except (OSError, ValueError):
@@ -402,7 +454,11 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, co
         curve = [p for p in gap_curve(gap_curve_sums(bt, best_known[:cores]), grid, 0.0) if p["t_s"] <= time_limit]
     phys, threads = physical_cores()
     per_core = 1.0 / search
-    return {"value": cores / wall, "unit": "instances/s", "cores": cores, "kind": "port",
+    raw = None
+    if best_known is not None:
+        raw = {"imp_cost": pad("imp_cost", np.inf), "imp_time": pad("imp_time", np.inf), "imp_len": np.array([o["imp_len"] for o in outs]),
+               "init_cost": np.asarray(init_cost[:cores]), "best_known": np.asarray(best_known[:cores])}
+    return {"_raw_traces": raw, "value": cores / wall, "unit": "instances/s", "cores": cores, "kind": "port",
             "per_core_value": per_core,
             # the same search-progress record as the GPU line's gap_vs_budget (the CPU leg is not charged the forward pass:
             # its budget clock is its search clock)
@@ -427,7 +483,7 @@ def cpu_baseline(D, guides, init_tour, init_cost, best_known, time_limit, pm, co
                                        "instances_per_s_per_core": 0.1, "source": "BASELINE.md section 2"}}
 
 
-def iso_quality_pass(args, n, chunk, model, scalers, pipeline):
+def iso_quality_pass(args, n, chunk, model, scalers, pipeline, trace=None, cpu=None):
     """Untimed extra pass (rank 0, N = 1): ISO_ROUNDS device loads of `chunk` instances searched within ONE time limit
     (budget="per_batch": the rounds share it, each instance is searched for time_limit / rounds including its forward
     pass) -- the throughput end of the budget-versus-quality trade, with the gap there to judge it.  This is the number
@@ -466,6 +522,27 @@ def iso_quality_pass(args, n, chunk, model, scalers, pipeline):
     pts = [point(args.time_limit / f) for f in ISO_FRONTIER]
     out = dict(pts[0])
     out["frontier"] = pts
+    # throughput at FIXED quality: the per-load budget at which the mean gap reaches each target, read from the improvement traces
+    # of the last timed step (a short search is the prefix of a long one: same kernel, same trajectory), then MEASURED: the same
+    # `rounds` device loads inside rounds x (pre-search + that search time); the CPU port's single-core rate at the same mean gaps
+    # from its own record beside it (search only: the CPU leg is not charged the forward pass)
+    if trace is not None:
+        t_gap = time_to_gap(trace["imp_cost"], trace["imp_time"], trace["imp_len"], trace["init_cost"], trace["best_known"],
+                            ISO_GAP_TARGETS, args.time_limit)
+        targets = []
+        for g, tg in zip(ISO_GAP_TARGETS, t_gap):
+            e = {"target_mean_gap_pct": g, "search_s_from_trace": tg, "pre_search_s": trace["pre_search_s"]}
+            if tg is not None:
+                m = point(rounds * (trace["pre_search_s"] + tg))
+                e.update({"predicted_instances_per_s": chunk / (trace["pre_search_s"] + tg), "measured": m,
+                          "instances_per_s": m["instances_per_s"], "measured_mean_gap_pct": m["mean_gap_pct"]})
+            if cpu is not None:
+                tc = time_to_gap(cpu["imp_cost"], cpu["imp_time"], cpu["imp_len"], cpu["init_cost"], cpu["best_known"], [g], args.time_limit)[0]
+                e["cpu_port_search_s"] = tc
+                e["cpu_port_instances_per_s_per_core"] = (1.0 / tc) if tc else None
+                e["cpu_port_sample_instances"] = int(len(cpu["init_cost"]))
+            targets.append(e)
+        out["at_fixed_quality"] = targets
     out["how"] = (f"{rounds} device loads of {chunk} instances (blocks 0.. of the seeded set) through solve_batch(budget='per_batch'): "
                   f"ONE limit for all of them, forward passes included; untimed passes after the timed steps at limits "
                   + ", ".join(f"{args.time_limit / f:g} s" for f in ISO_FRONTIER) + " (`frontier`; the top-level fields are the first)")
@@ -649,9 +726,12 @@ def main():
         if int(rc.evals_executed.min()) >= 0:
             exec_ratio = float(rc.evals_executed.sum()) / max(float(rc.evals.sum()), 1.0)
             rec = [x.double().cpu().numpy() for x in rc.timing.get("cycle_records", [])]
-            if len(rec) == 4 and rec[0].sum() > 0:
+            if len(rec) >= 4 and rec[0].sum() > 0:
                 cyc = {"kernel_cycles": rec[0], "pert_cycles": rec[1], "steps": rec[2], "ticks": rec[3],
                        "outer_iters": rc.outer_iters.double().cpu().numpy()}
+                if len(rec) >= 14:           # ABI v4: the cycle account of the descent (include/gnngls_hip.h, GNNGLS_EXEC_RECORDS)
+                    cyc.update({"descent_cycles": rec[4], "scans": [rec[5], rec[7], rec[9]], "scan_cycles": [rec[6], rec[8], rec[10]],
+                                "argmin_cycles": rec[11], "apply_cycles": rec[12], "moves": rec[13]})
 
     if rank == 0:
         g = gathered.cpu().numpy()                                             # [total, 5], all ranks' instances in order
@@ -778,8 +858,15 @@ def main():
                                                bk, args.time_limit, args.perturbation_moves, cores)
             wb = out["cpu_baseline"]["whole_box_estimate"]
             wb["gpu_over_whole_box"] = value / wb["instances_per_s"] if wb["instances_per_s"] > 0 else None
+        cpu_raw = out.get("cpu_baseline", {}).pop("_raw_traces", None) if "cpu_baseline" in out else None
         if world == 1 and not args.no_iso_quality and not strong and not args.exact_gap:
-            out["iso_quality"] = iso_quality_pass(args, n, resident, model, scalers, pipeline)
+            trace = None
+            if bk_local is not None and B > 0 and last.imp_cost is not None:
+                m = min(resident, B)
+                trace = {"imp_cost": last.imp_cost[:m].cpu().numpy(), "imp_time": last.imp_time[:m].cpu().numpy(),
+                         "imp_len": last.imp_len[:m].cpu().numpy(), "init_cost": last.init_cost[:m].cpu().numpy(),
+                         "best_known": bk_local[:m], "pre_search_s": pre_search}
+            out["iso_quality"] = iso_quality_pass(args, n, resident, model, scalers, pipeline, trace, cpu_raw)
         print(json.dumps(out))
     if grouped:
         dist.barrier()

@@ -336,7 +336,7 @@ int gnngls_gls_run(const double *D, const double *guides, int n_guides, int B, i
     if (A.evals_exec) {          // the wavefronts of an instance add their counts atomically
         // a run that prunes on an instantiation without the counting code cannot report the executed evaluations: -1
         const bool unknown = cfg.prune && !gnngls::gls_count_supported(cfg.store, cfg.wps, n, first_improvement != 0, A.trace_cap > 0);
-        e = hipMemsetAsync(A.evals_exec, 0, (size_t)5 * B * sizeof(long long), st);       // counts + the four cycle records
+        e = hipMemsetAsync(A.evals_exec, 0, (size_t)GNNGLS_EXEC_RECORDS * B * sizeof(long long), st);       // counts + the cycle records
         if (e == hipSuccess && unknown) e = hipMemsetAsync(A.evals_exec, 0xff, (size_t)B * sizeof(long long), st);
         if (e != hipSuccess) { if (ws) (void)hipFreeAsync(ws, st); return hip_fail(e, "gls_run: executed-evaluations buffer"); }
         if (unknown) A.evals_exec = nullptr;

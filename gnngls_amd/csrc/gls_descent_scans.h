@@ -210,6 +210,7 @@ __device__ __forceinline__ void block_reduce_best_lds(Ctl *ctl, int &phase, int 
     typedef __attribute__((address_space(3))) unsigned lds_u32_t;
     lds_u64_t *av = (lds_u64_t *)reinterpret_cast<unsigned long long *>(&ctl->red_d[0][0]);
     lds_u32_t *ak = (lds_u32_t *)reinterpret_cast<unsigned *>(&ctl->red_k[0][0]);
+    ISA_MARK("argmin_lds_begin");
     const int sl = phase, nx = phase == 2 ? 0 : phase + 1;
     const bool cand = k != kNoKey;
     const unsigned long long sk = sortable(d);
@@ -227,6 +228,7 @@ __device__ __forceinline__ void block_reduce_best_lds(Ctl *ctl, int &phase, int 
     __syncthreads();
     k = (int)ak[sl];
     d = unsortable(m);
+    ISA_MARK("argmin_lds_end");
 }
 
 // ---- lean "row on the lane" scans (best improvement, symmetric stores, n <= 255) -------------------------------------
@@ -577,6 +579,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     const int rb = __builtin_amdgcn_readfirstlane(wave / (per_rb > 0 ? per_rb : 1));
     const int part = __builtin_amdgcn_readfirstlane(wave - rb * per_rb);
     if (per_rb == 0 || rb >= RW) return;                     // callers guarantee nwaves >= RW; surplus waves idle
+    ISA_MARK("reloc_lean_begin");
     const LaneTour<SL> L = load_lane_tour<SL>(t, n, lane);
     const int own = 1 + rb * kWave + lane;                   // the lane's row: a position, or a node id (pos != nullptr)
     const bool row_ok = own <= n - 1;                        // permutations(range(1,n),2), skip i-j == 1 (operators.py:133-136)
@@ -601,6 +604,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
     auto group = [&](int k, int te, auto ucount, auto fast_addr) {        // te: the register slot holding positions k+1 .. k+U
         constexpr int U = decltype(ucount)::value;
         constexpr bool FA = decltype(fast_addr)::value;      // every t[k+1] of the group is a node >= 1
+        if constexpr (U > 1) ISA_MARK("reloc_lean_group"); else ISA_MARK("reloc_lean_single");
         double ve[U], de[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -625,6 +629,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
         } else {
             if (!group_may_improve<MF>(dl, bd)) return;      // one exec-masked region per group instead of one per step
         }
+        ISA_MARK("reloc_lean_candidates");
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = k + u;
@@ -654,6 +659,7 @@ __device__ __forceinline__ void scan_relocate_a2a_lean(const S &s, const TT *t, 
         for (int q = 0; q < SL; ++q)                         // the slot that holds position n
             if (n / kWave == q) group(n - 1, L.t[q], U1{}, EXACT{});
     }
+    ISA_MARK("reloc_lean_end");
     if constexpr (QT) {
         // rows some delta of which is below the quiet threshold stay active (the two garbage steps k in {i-1, i} included: a spurious
         // bit costs one exact re-evaluation of the row by the next reduced scan, never a lost move)
@@ -907,7 +913,9 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
     const int tasks = 8 * (n - 1);                           // 8 lanes per tour row, two list entries per lane and level
     const int rowbit = (lane & 56) + 7;                      // lane that holds entries 15 / 31 of this lane's row
     int it = 0;
+    ISA_MARK("twoopt_pruned_begin");
     for (int task0 = 0; task0 < tasks; task0 += nthr, ++it) {      // wave-uniform trip count; a wavefront's tasks are whole rows
+        ISA_MARK("twoopt_pruned_pass");
         const int task = task0 + tid;
         const bool live = task < tasks;
 #if GLS_SKIP_DEAD_PASS
@@ -925,6 +933,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
         bool more = live;                                    // the row may hold candidates among its next 16 list entries
 #pragma unroll 1
         for (int lvl = 0; lvl < 2; ++lvl) {
+            ISA_MARK("twoopt_pruned_level");
             const int y0 = (ids4 >> (16 * lvl)) & 0xff, y1 = (ids4 >> (16 * lvl + 8)) & 0xff;     // entries m and m + 8 of this level
             const double d0 = s.dist(x, y0), d1 = s.dist(x, y1);
             const int q0 = pos[y0], q1 = pos[y1];
@@ -939,6 +948,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
                 const bool cb = act && d < es && q <= p - 2 && p <= n - 2;
                 if constexpr (CNT) xe += __popcll(__ballot(ca || cb));
                 if (ca || cb) {
+                    ISA_MARK("twoopt_pruned_candidate");
                     const int o2 = t[ca ? q - 1 : q + 1];
                     const double e2 = Ef[ca ? q : q + 1];
                     const double dpair = s.dist(ca ? xm : xp, o2);       // D[b,d] (A) / D[a,c] (B)
@@ -954,6 +964,7 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
             if (!need) break;
         }
         // all 32 entries below the row's threshold: every move that has x as `a` (row p) or as `d` (column p + 1)
+        ISA_MARK("twoopt_pruned_overflow");
         unsigned long long om = __ballot(more && m == 7);
 #ifdef GLS_STAMPS
         if (dbg && lane == 0) { dbg[0] += __popcll(om); dbg[2] += 1; }

@@ -83,10 +83,17 @@ struct PruneCtx {
     NlWords nlw; bool on;
 };
 
+// cycle account of the descent (counting instantiations only; bench.py's critical_path record): shader cycles of this wavefront
+// in the scans of each kind, in the workgroup arg-min (incl. waiting for the slowest wavefront) and in move application + barrier
+struct DescentCycles {
+    long long scans[3] = {0, 0, 0}, cycles[3] = {0, 0, 0};      // 0: two_opt_a2a, 1: relocate_a2a in full, 2: relocate_a2a over the flagged rows
+    long long argmin = 0, apply = 0, moves = 0;
+};
+
 template <class S, bool FI, int GP, bool CNT, int WPS, class TT, class TRC>
 __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, long long &xe, Stamps &st,
-                                 TT *ppos, const PruneCtx &pc) {
+                                 TT *ppos, const PruneCtx &pc, DescentCycles &dc) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -152,6 +159,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
         for (int op = 0; op < 2; ++op) {                             // algorithms.py:119
             double bd = 0.0; int bk = kNoKey;
             bool lean = false, pruned_scan = false, quiet_scan = false;
+            long long cyc0 = 0;
+            if constexpr (CNT) cyc0 = clock64();
             int xs = 0;          // evaluations this wavefront executes in a pruned scan (scalar; booked once per scan below)
             if constexpr (kCanPrune) {
                 int nlong = 0;
@@ -237,8 +246,15 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             if (!kPruneRelocate && op == 1) st.acc[15] += clock64() - st.t0;       // relocate's share of the scan cycles (GP = 2 builds)
 #endif
             STAMP_END(8);    // a2a scan (this wave's share)
+            long long cyc1 = 0;
+            if constexpr (CNT) {
+                cyc1 = clock64();
+                const int kind = op == 0 ? 0 : quiet_scan ? 2 : 1;
+                dc.scans[kind] += 1; dc.cycles[kind] += cyc1 - cyc0;
+            }
             if (!FI && nwaves > 1) block_reduce_best_lds(ctl, phase, tid, bd, bk);
             else block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
+            if constexpr (CNT) { cyc0 = clock64(); dc.argmin += cyc0 - cyc1; }
             if constexpr (kQuietRows) {
                 // every wavefront has consumed the pending records and the rows to flag (two barriers ago at least): the wavefront that
                 // notes the moves (the last one) clears them, in program order before it notes this scan's own move
@@ -252,6 +268,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             if (CNT && pruned_scan)
                 xe += xs - (wave_u == 0 ? ((op == 0) ? (n - 2) * (n - 3) / 2 : (n - 2) * (n - 2)) : 0);
             if (bk != kNoKey) {                                      // delta < 0 (algorithms.py:122)
+                ISA_MARK("descent_apply_begin");
                 improved = true;
                 cur_cost += bd;                                      // algorithms.py:124
                 apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos, prune ? ppos : nullptr, ctl, Lmax);
@@ -263,6 +280,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 if (tid == 0) tr.push(cur_cost);
                 __syncthreads();
                 if (prune) Lmax = unsortable(*lmax_slot(ctl));
+                ISA_MARK("descent_apply_end");
+                if constexpr (CNT) { dc.apply += clock64() - cyc0; dc.moves += 1; }
                 STAMP_END(10);   // move application + barrier
             }
         }
@@ -409,7 +428,9 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         }
     }
     long long xe = 0;        // executed minus reference-equivalent evaluations of this wavefront's pruned scans (CNT builds)
-    local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);   // algorithms.py:142
+    DescentCycles dc, dc_first;
+    long long descent_cycles = 0;
+    local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc, dc_first);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
     for (int p = tid; p <= n; p += nthr) bt[p] = (int32_t)t[p];
@@ -572,7 +593,10 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
 
         // ---- optimisation (algorithms.py:188) ----
         STAMP_BEGIN();
-        local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc);
+        long long dcy0 = 0;
+        if constexpr (CNT) dcy0 = clock64();
+        local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc, dc);
+        if constexpr (CNT) descent_cycles += clock64() - dcy0;
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -609,6 +633,14 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
             A.evals_exec[(size_t)2 * A.B + b] = pert_cycles;
             A.evals_exec[(size_t)3 * A.B + b] = pert_steps;
             A.evals_exec[(size_t)4 * A.B + b] = wall_clock64() - t_start;
+            // ... and of the descent of the outer iterations (wavefront 0; the start descent of algorithms.py:142 is not in it):
+            // total, then per scan kind (two_opt_a2a, relocate_a2a in full, relocate_a2a over flagged rows) count and cycles,
+            // workgroup arg-min (+ waiting for the slowest wavefront), move application + barrier, accepted moves
+            long long *o = A.evals_exec + (size_t)5 * A.B;
+            o[b] = descent_cycles;
+            for (int q = 0; q < 3; ++q) { o[(size_t)(1 + 2 * q) * A.B + b] = dc.scans[q]; o[(size_t)(2 + 2 * q) * A.B + b] = dc.cycles[q]; }
+            o[(size_t)7 * A.B + b] = dc.argmin; o[(size_t)8 * A.B + b] = dc.apply; o[(size_t)9 * A.B + b] = dc.moves;
+            o[(size_t)10 * A.B + b] = 0;
         }
     } else if (A.evals_exec && tid == 0) {
         // the host only hands this instantiation the buffer when no scan of the run is pruned: executed = reference count

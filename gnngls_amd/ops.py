@@ -240,6 +240,9 @@ class gls_prune_mode:
         return False
 
 
+EXEC_RECORDS = 16        # GNNGLS_EXEC_RECORDS of include/gnngls_hip.h
+
+
 class executed_evals:
     """Measurement hook (gnngls_profile_set_executed_evals): `with executed_evals(B_max) as x: gls_run(...)` -> x.counts
     [B_max] int64 holds, for the LAST gls_run launch inside the block, the delta evaluations the kernel actually executed
@@ -249,11 +252,12 @@ class executed_evals:
 
     def __init__(self, capacity):
         self.capacity = int(capacity)
-        self.buffer = torch.zeros((5 * self.capacity,), dtype=torch.int64, device=_dev())
+        self.buffer = torch.zeros((EXEC_RECORDS * self.capacity,), dtype=torch.int64, device=_dev())
 
     def record(self, B, k):
         """Record k of the LAST launch of B instances inside the block: 0 executed evaluations, 1 shader cycles of the
-        workgroup, 2 shader cycles of its serial perturbation phase, 3 penalty steps of that phase, 4 100 MHz ticks."""
+        workgroup, 2 shader cycles of its serial perturbation phase, 3 penalty steps of that phase, 4 100 MHz ticks, 5 .. 14 the
+        cycle account of the descent (include/gnngls_hip.h, GNNGLS_EXEC_RECORDS)."""
         return self.buffer[k * B:(k + 1) * B]
 
     @property

@@ -148,7 +148,7 @@ def solve_batch(D, model=None, scalers=None, guides=("regret_pred",), time_limit
             with ops.executed_evals(Dc.shape[0]) as x:
                 r = run()
             executed = x.counts
-            timing["cycle_records"] = [x.record(Dc.shape[0], k).clone() for k in (1, 2, 3, 4)]     # of the last device load
+            timing["cycle_records"] = [x.record(Dc.shape[0], k).clone() for k in range(1, ops.EXEC_RECORDS)]     # of the last device load
         else:
             r = run()
         torch.cuda.synchronize()

@@ -282,8 +282,14 @@ int gnngls_profile_collect(double *ms_by_kind, int64_t *launches_by_kind);
  * ABI v3: the buffer holds 5 x B int64 -- [0, B) the counts above, then four records of the same launch for bench.py's
  * critical-path figure (written by the counting instantiations, else 0): [B, 2B) shader cycles of the instance's workgroup,
  * [2B, 3B) shader cycles of its serial perturbation phase (algorithms.py:150-185, wavefront 0), [3B, 4B) penalty steps of
- * that phase (edge form), [4B, 5B) 100 MHz device-clock ticks of the workgroup.  It must hold 5 x the largest B launched
- * while it is set; process-wide, not per stream. */
+ * that phase (edge form), [4B, 5B) 100 MHz device-clock ticks of the workgroup.
+ * ABI v4: GNNGLS_EXEC_RECORDS = 16 records of B int64 -- after the five above the cycle account of the descent of the outer
+ * iterations (algorithms.py:188 -> 111-132; wavefront 0 of the workgroup): [5B, 6B) shader cycles in local_search, then count and
+ * cycles of the two_opt_a2a scans [6B, 8B), of the relocate_a2a scans evaluated in full [8B, 10B) and over the flagged rows only
+ * [10B, 12B) (operators.py:32-50,129-147), [12B, 13B) cycles of the workgroup arg-min incl. waiting for the slowest wavefront,
+ * [13B, 14B) of move application + barrier (algorithms.py:122-126), [14B, 15B) accepted moves, [15B, 16B) reserved.
+ * The buffer must hold GNNGLS_EXEC_RECORDS x the largest B launched while it is set; process-wide, not per stream. */
+#define GNNGLS_EXEC_RECORDS 16
 int gnngls_profile_set_executed_evals(int64_t *device_buffer);
 
 #ifdef __cplusplus

@@ -40,71 +40,70 @@ def test_bench_line_has_the_contract_keys():
 
 
 def test_roofline_and_cpu_baseline_objects():
-    """Every fraction of the committed line is re-derived from the line's own numbers, and is <= 1 by construction: the
-    primary one is a counter ratio (busy vector-ALU cycles / SIMD cycles), the live one counts EXECUTED evaluations."""
+    """Every fraction of the committed line is re-derived from the line's own numbers.  Round 6 froze the primary one: SURVEY
+    8(d)'s executed-LDS figure (executed delta evaluations x their algorithmic LDS bytes / aggregate LDS rate), measured in the run;
+    the counters, the critical path of the serial phase and the issue model of the descent scans are side records."""
     j = latest_bench()
     r = j["roofline"]
     assert r["kernel"] == "gls_kernel" and r["launches"] == j["steps"] * j["config"]["rounds_per_rank"][0]
-    if r["bound"] == "lds":                                        # lines of rounds 1-3: the algorithmic LDS figure only
-        assert r["unit"] == "GB/s" and r["peak"] == 150000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
-    else:
-        pmc = r["pmc"]
-        if "critical_path" in r:
-            # round 5: the primary fraction is MEASURED in the run -- penalty steps per second of an instance against the rate the
-            # dependent chain of a step allows (committed chain floor / measured cycles per step) -- and `bound` is derived from
-            # the counters: no pipe above 60 % busy while the wavefronts wait for more than half of their cycles = "latency"
-            cp = r["critical_path"]
-            assert r["unit"] == "penalty steps/s per instance" and "measured in this run" in r["frac_source"]
-            assert abs(r["frac"] - cp["floor_cycles"] / cp["measured_cycles"]) < 1e-9 and 0 < r["frac"] <= 1
-            assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and abs(r["achieved"] - cp["clock_ghz"] * 1e9 / cp["measured_cycles"]) < 1e-6 * r["achieved"]
-            assert 1.5 < cp["clock_ghz"] < 2.5 and 10 < cp["penalty_steps_per_outer_iteration"] < 25 and 0.2 < cp["share_of_kernel_cycles"] < 0.8
-            committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa", "critical_path.json")))["tsp%d" % j["config"]["n"]]
-            assert cp["floor_cycles"] == committed["chain_floor_cycles_per_step"] and cp.get("issue_model_cycles", cp.get("issue_floor_cycles")) == committed["issue_model_cycles_per_step"]
-            busiest = max(v for k, v in pmc.items() if k.endswith("_busy_frac"))
-            assert r["bound"] == ("latency" if busiest <= 0.6 and pmc["wave_wait_frac"] > 0.5 else r["binding_resource"]["name"])
-            assert "PMC counters" in r["bound_source"]
-        else:
-            assert r["bound"] == "valu_issue" and r["unit"] == "G SIMD-cycles/s"
-            assert abs(r["frac"] - pmc["valu_busy_frac"]) < 1e-12 and 0 < r["frac"] <= 1
-            assert abs(r["peak"] - 1024 * pmc["clock_ghz"]) < 1e-9 * r["peak"] and abs(r["achieved"] - r["frac"] * r["peak"]) < 1e-9 * r["peak"]
-        # the counters were collected on the workload of the line itself
-        assert r["pmc_matches_workload"] and pmc["workload"]["n"] == j["config"]["n"] and pmc["workload"]["guide"] == "model"
-        # live part: executed <= reference-equivalent evaluations; LDS bytes of the executed ones against the aggregate rate
-        assert 0 < r["executed_evals_per_s"] <= r["reference_equivalent_evals_per_s"]
-        assert abs(r["prune_ratio"] - r["executed_evals_per_s"] / r["reference_equivalent_evals_per_s"]) < 1e-9
-        le = r["lds_executed"]
-        assert le["peak"] == 150000.0 and abs(le["achieved"] - r["executed_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9) < 1e-6 * le["achieved"]
-        assert abs(le["frac"] - le["achieved"] / le["peak"]) < 1e-12 and 0 < le["frac"] <= 1
-        assert abs(r["reference_equivalent_frac"] - r["reference_equivalent_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9 / 150000.0) < 1e-9
-        b = r["binding_resource"]
-        busy = {k[:-len("_busy_frac")]: v for k, v in pmc.items() if k.endswith("_busy_frac")}
-        order = sorted(busy, key=busy.get, reverse=True)
-        assert b["name"] == order[0] + "_issue" and b["frac"] == busy[order[0]] and b["second"] == order[1]
-        # gap-versus-budget of the same timed step: never rises, ends at the headline gap
-        c = j["gap_vs_budget"]
-        assert len(c) >= 3 and all(a["t_s"] < b_["t_s"] for a, b_ in zip(c, c[1:]))
-        assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(c, c[1:]))
-        assert abs(c[-1]["mean_gap_pct"] - j["mean_gap_pct"]) < 1e-9 and abs(c[-1]["budget_t_s"] - j["config"]["time_limit_s"]) < 1e-6
-        q = j["iso_quality"]
-        assert q["budget"] == "per_batch" and q["rounds"] >= 2 and abs(q["instances_per_s"] - q["instances"] / q["wall_s"]) < 1e-9 * q["instances_per_s"]
-        assert q["wall_s"] < 1.1 * q["time_limit_s"] + 1.0 and q["instances_per_s"] > 2 * j["value"]
-        if "frontier" in q:                                       # round 5: the same loads inside the full limit, a third, a tenth
-            f = q["frontier"]
-            assert len(f) == 3 and f[0]["instances_per_s"] == q["instances_per_s"] and all(0 < p["forward_share"] < 1.2 for p in f)
-            assert f[0]["instances_per_s"] < f[1]["instances_per_s"] < f[2]["instances_per_s"]
-            assert f[0]["mean_gap_pct"] <= f[1]["mean_gap_pct"] <= f[2]["mean_gap_pct"]
-        if j.get("true_gap_exact_sample"):                        # gap against PROVEN optima (branch and bound, checker side)
-            e = j["true_gap_exact_sample"]
-            assert e["instances"] >= 64 and e["mean_gap_pct"] >= -1e-9 and "bench_data/exact_optima" in e["source"]
-        w = j["cpu_baseline"]["whole_box_estimate"]
-        assert abs(w["instances_per_s"] - j["cpu_baseline"]["per_core_value"] * w["physical_cores"]) < 1e-9 * w["instances_per_s"]
-        assert abs(w["gpu_over_whole_box"] - j["value"] / w["instances_per_s"]) < 1e-9 * w["gpu_over_whole_box"]
-        cc = j["cpu_baseline"]["gap_vs_budget"]
-        assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(cc, cc[1:]))
+    assert r["bound"] == "lds" and r["unit"] == "GB/s" and r["peak"] == 150000.0 and "SURVEY 8(d)" in r["frac_definition"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1 and r["frac_source"] == "measured in this run"
+    assert 0 < r["executed_evals_per_s"] <= r["reference_equivalent_evals_per_s"]
+    assert abs(r["prune_ratio"] - r["executed_evals_per_s"] / r["reference_equivalent_evals_per_s"]) < 1e-9
+    assert abs(r["achieved"] - r["executed_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["reference_equivalent_frac"] - r["reference_equivalent_evals_per_s"] * r["lds_bytes_per_eval"] / 1e9 / 150000.0) < 1e-9
+    # the counters were collected on the workload of the line itself; two busiest pipes, sorted, no label
+    pmc = r["pmc"]
+    assert r["pmc_matches_workload"] and pmc["workload"]["n"] == j["config"]["n"] and pmc["workload"]["guide"] == "model"
+    busy = {k[:-len("_busy_frac")]: v for k, v in pmc.items() if k.endswith("_busy_frac")}
+    order = sorted(busy, key=busy.get, reverse=True)
+    assert [p["pipe"] for p in r["busiest_pipes"]] == order[:2] and r["wave_wait_frac"] == pmc["wave_wait_frac"]
+    # critical path: the penalty step against its committed chain floor, the descent scans against their committed issue model,
+    # and the two phases together cover the kernel's cycles
+    cp = r["critical_path"]
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa", "critical_path.json")))["tsp%d" % j["config"]["n"]]
+    assert cp["floor_cycles"] == committed["chain_floor_cycles_per_step"] and abs(cp["frac"] - cp["floor_cycles"] / cp["measured_cycles"]) < 1e-9
+    assert 1.5 < cp["clock_ghz"] < 2.5 and 10 < cp["penalty_steps_per_outer_iteration"] < 25 and 0.2 < cp["share_of_kernel_cycles"] < 0.8
+    d = cp["descent"]
+    model = json.load(open(os.path.join(ROOT, "profiles", "r06_isa", "descent_model.json")))["tsp%d" % j["config"]["n"]]
+    assert cp["coverage_of_kernel_cycles"] >= 0.9 and abs(cp["coverage_of_kernel_cycles"] - cp["share_of_kernel_cycles"] - d["share_of_kernel_cycles"]) < 1e-9
+    for key, sc in d["scans"].items():
+        assert sc["issue_model_cycles"] == model[key]["issue_model_cycles"] and abs(sc["measured_over_issue_model"] - sc["measured_cycles"] / sc["issue_model_cycles"]) < 1e-9
+        assert 0.8 < sc["measured_over_issue_model"] < 2.5
+    # one full relocate scan per descent, the others over the flagged rows only; as many 2-opt scans as relocate scans
+    assert abs(d["scans"]["relocate_full"]["per_outer_iteration"] - 1.0) < 1e-9
+    assert abs(d["scans"]["two_opt"]["per_outer_iteration"] - 1.0 - d["scans"]["relocate_flagged"]["per_outer_iteration"]) < 1e-6
+    # gap-versus-budget of the same timed step: never rises, ends at the headline gap
+    c = j["gap_vs_budget"]
+    assert len(c) >= 3 and all(a["t_s"] < b_["t_s"] for a, b_ in zip(c, c[1:]))
+    assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(c, c[1:]))
+    assert abs(c[-1]["mean_gap_pct"] - j["mean_gap_pct"]) < 1e-9 and abs(c[-1]["budget_t_s"] - j["config"]["time_limit_s"]) < 1e-6
+    q = j["iso_quality"]
+    assert q["budget"] == "per_batch" and q["rounds"] >= 2 and abs(q["instances_per_s"] - q["instances"] / q["wall_s"]) < 1e-9 * q["instances_per_s"]
+    assert q["wall_s"] < 1.1 * q["time_limit_s"] + 1.0 and q["instances_per_s"] > 2 * j["value"]
+    f = q["frontier"]
+    assert len(f) == 3 and f[0]["instances_per_s"] == q["instances_per_s"] and all(0 < p["forward_share"] < 1.2 for p in f)
+    assert f[0]["instances_per_s"] < f[1]["instances_per_s"] < f[2]["instances_per_s"]
+    assert f[0]["mean_gap_pct"] <= f[1]["mean_gap_pct"] <= f[2]["mean_gap_pct"]
+    # throughput at fixed quality: three targets, measured passes within 15 % of their gap target, faster for the looser target,
+    # the CPU port's single-core rate at the same mean gap beside each
+    t = q["at_fixed_quality"]
+    assert [e["target_mean_gap_pct"] for e in t] == [0.1, 0.03, 0.01]
+    assert all(abs(e["measured_mean_gap_pct"] - e["target_mean_gap_pct"]) < 0.15 * e["target_mean_gap_pct"] for e in t)
+    assert t[0]["instances_per_s"] > t[1]["instances_per_s"] > t[2]["instances_per_s"] > q["instances_per_s"]
+    assert all(e["cpu_port_instances_per_s_per_core"] > 0 and e["instances_per_s"] > 100 * e["cpu_port_instances_per_s_per_core"] for e in t)
+    e = j["true_gap_exact_sample"]                            # gap against PROVEN optima (branch and bound, checker side)
+    assert e["instances"] >= 64 and e["mean_gap_pct"] >= -1e-9 and "bench_data/exact_optima" in e["source"]
+    assert j["true_gap_bracket"]["bound_above_known_tour_instances"] == 0
+    w = j["cpu_baseline"]["whole_box_estimate"]
+    assert abs(w["instances_per_s"] - j["cpu_baseline"]["per_core_value"] * w["physical_cores"]) < 1e-9 * w["instances_per_s"]
+    assert abs(w["gpu_over_whole_box"] - j["value"] / w["instances_per_s"]) < 1e-9 * w["gpu_over_whole_box"]
+    cc = j["cpu_baseline"]["gap_vs_budget"]
+    assert all(a["mean_gap_pct"] >= b_["mean_gap_pct"] - 1e-12 for a, b_ in zip(cc, cc[1:]))
     for k in j["kernels"].values():
         assert k["bound"] in ("hbm", "mfma") and (k["peak"] in (8000.0, 157.3) or abs(k["peak"] - 16 * 157.3 / 6) < 1e-6)      # (bf16 MFMA peak / 6: the bf16x3 feed-forward block)
     c = j["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and "_raw_traces" not in c
     assert c["per_core_value"] > 0 and "all" in c["sample"]
 
 
@@ -128,6 +127,19 @@ def test_search_progress_record_helpers():
     assert bt0.tolist() == [[3.], [4.]]
     cores, threads = b.physical_cores()
     assert 1 <= cores <= threads
+
+
+def test_time_to_gap_reads_the_improvement_traces():
+    """bench.py's fixed-quality frontier: the search time after which the MEAN gap first meets a target."""
+    b = bench_module()
+    # two instances with best-known 10: instance 0 reaches 10.1 at 0.5 s and 10 at 2 s; instance 1 reaches 10 at 0.1 s
+    imp_cost = np.array([[12., 10.1, 10., 10.], [10., 10., 0., 0.]])
+    imp_time = np.array([[0.01, 0.5, 2.0, 9.9], [0.1, 9.9, 0., 0.]])
+    imp_len = np.array([4, 2])
+    t = b.time_to_gap(imp_cost, imp_time, imp_len, np.array([20., 20.]), np.array([10., 10.]), [15.0, 0.6, 0.51, 0.0, -1.0], 10.0)
+    assert abs(t[0] - 0.1) < 0.003          # mean gap 10 % from 0.1 s on: (20 % + 0 %) / 2
+    assert abs(t[1] - 0.5) < 0.011 and abs(t[2] - 0.5) < 0.011          # 0.5 % from 0.5 s on
+    assert abs(t[3] - 2.0) < 0.041 and t[4] is None
 
 
 def test_search_roofline_object_is_self_consistent():

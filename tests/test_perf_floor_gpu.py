@@ -1,9 +1,10 @@
 """Speed floors of the search kernel on the BASELINE.json shapes (round-4 review item 5): gls_kernels.hip is ~70 template
 instantiations whose code generation moves with unrelated edits; a regression there changes no result, so the parity tests
 cannot see it.  One second of search per shape with the bench's own guide (regret_pred of the synthetic model): the mean outer
-iterations must reach 85 % of the committed rate (profiles/r05_iteration_rates.json, same probe on the round's GPU boxes; box to
-box the rate moves by a few percent, a fall-back to the round-4 code paths costs 15-27 %), and the instantiation each shape runs
-on must have no scratch (TSP200: a bounded amount outside the loops)."""
+iterations must reach 90 % of the committed MEDIAN rate (profiles/r06_iteration_rates.json: scripts/iteration_rates.py, median of
+five runs on the round's GPU boxes; box to box the rate moves by a few percent, losing the quiet rows of the relocate scan costs 10 %,
+a fall-back to the round-4 code paths 25-35 %), and the instantiation each shape runs on must have no scratch (TSP200: a bounded
+amount outside the loops)."""
 import json
 import os
 
@@ -13,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RATES = json.load(open(os.path.join(ROOT, "profiles", "r05_iteration_rates.json")))
+RATES = json.load(open(os.path.join(ROOT, "profiles", "r06_iteration_rates.json")))
 
 
 @pytest.mark.parametrize("shape", sorted(RATES["shapes"]))
@@ -40,4 +41,4 @@ def test_iteration_rate_floor_and_no_scratch(shape):
     torch.cuda.synchronize()
     assert int(r.status.sum()) == 0
     rate = float(r.outer_iters.double().mean())
-    assert rate >= 0.85 * spec["outer_iters_per_s"], f"{shape}: {rate:.0f} outer iterations in 1 s, committed {spec['outer_iters_per_s']:.0f}"
+    assert rate >= 0.9 * spec["outer_iters_per_s"], f"{shape}: {rate:.0f} outer iterations in 1 s, committed {spec['outer_iters_per_s']:.0f}"
