@@ -83,17 +83,23 @@ struct PruneCtx {
     NlWords nlw; bool on;
 };
 
-// cycle account of the descent (counting instantiations only; bench.py's critical_path record): shader cycles of this wavefront
-// in the scans of each kind, in the workgroup arg-min (incl. waiting for the slowest wavefront) and in move application + barrier
+// cycle account of the descent (counting instantiations only; bench.py's critical_path record): shader cycles of wavefront 0 in the
+// scans of each kind, in the workgroup arg-min (incl. waiting for the slowest wavefront) and in move application + barrier.  Thread
+// 0 adds them straight to the instance's records in global memory (returnless atomics: no accumulators live across the kernel --
+// nine 64-bit counters in registers made the counting build 18 % slower than the product it is meant to describe).
+//   rec[q * B]: 0 descent cycles, 1/2 count and cycles of two_opt_a2a, 3/4 of relocate_a2a in full, 5/6 of relocate_a2a over the
+//   flagged rows, 7 arg-min, 8 move application, 9 accepted moves   (include/gnngls_hip.h, records 5 .. 14)
 struct DescentCycles {
-    long long scans[3] = {0, 0, 0}, cycles[3] = {0, 0, 0};      // 0: two_opt_a2a, 1: relocate_a2a in full, 2: relocate_a2a over the flagged rows
-    long long argmin = 0, apply = 0, moves = 0;
+    long long *rec; size_t B;
+    __device__ __forceinline__ void add(int q, long long v) const {
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(rec + (size_t)q * B), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
 template <class S, bool FI, int GP, bool CNT, int WPS, class TT, class TRC>
 __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, double *Ef, double *Eb, int n,
                                  Ctl *ctl, int &phase, double &cur_cost, TRC &tr, long long &evals, long long &xe, Stamps &st,
-                                 TT *ppos, const PruneCtx &pc, DescentCycles &dc) {
+                                 TT *ppos, const PruneCtx &pc, const DescentCycles &dc) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = nthr >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -250,11 +256,11 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             if constexpr (CNT) {
                 cyc1 = clock64();
                 const int kind = op == 0 ? 0 : quiet_scan ? 2 : 1;
-                dc.scans[kind] += 1; dc.cycles[kind] += cyc1 - cyc0;
+                if (tid == 0 && dc.rec) { dc.add(1 + 2 * kind, 1); dc.add(2 + 2 * kind, cyc1 - cyc0); }
             }
             if (!FI && nwaves > 1) block_reduce_best_lds(ctl, phase, tid, bd, bk);
             else block_reduce_best<FI>(ctl, phase, wave, nwaves, lane, bd, bk);
-            if constexpr (CNT) { cyc0 = clock64(); dc.argmin += cyc0 - cyc1; }
+            if constexpr (CNT) { cyc0 = clock64(); if (tid == 0 && dc.rec) dc.add(7, cyc0 - cyc1); }
             if constexpr (kQuietRows) {
                 // every wavefront has consumed the pending records and the rows to flag (two barriers ago at least): the wavefront that
                 // notes the moves (the last one) clears them, in program order before it notes this scan's own move
@@ -281,7 +287,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 __syncthreads();
                 if (prune) Lmax = unsortable(*lmax_slot(ctl));
                 ISA_MARK("descent_apply_end");
-                if constexpr (CNT) { dc.apply += clock64() - cyc0; dc.moves += 1; }
+                if constexpr (CNT) { if (tid == 0 && dc.rec) { dc.add(8, clock64() - cyc0); dc.add(9, 1); } }
                 STAMP_END(10);   // move application + barrier
             }
         }
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         }
     }
     long long xe = 0;        // executed minus reference-equivalent evaluations of this wavefront's pruned scans (CNT builds)
-    DescentCycles dc, dc_first;
-    long long descent_cycles = 0;
+    // (the start descent of algorithms.py:142 is not in the account: rec = nullptr)
+    const DescentCycles dc_first{nullptr, 0}, dc{(CNT && A.evals_exec) ? A.evals_exec + (size_t)5 * A.B + b : nullptr, (size_t)A.B};
     local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc, dc_first);   // algorithms.py:142
     double best_cost = cur_cost;                                              // algorithms.py:143
     if (tid == 0) push_improvement(best_cost, 0);
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
         long long dcy0 = 0;
         if constexpr (CNT) dcy0 = clock64();
         local_search_dev<S, FI, GP, CNT, WPS>(s, t, t2, Ef, Eb, n, ctl, phase, cur_cost, tr, evals, xe, st, ppos, pc, dc);
-        if constexpr (CNT) descent_cycles += clock64() - dcy0;
+        if constexpr (CNT) { if (tid == 0 && dc.rec) dc.add(0, clock64() - dcy0); }
         STAMP_END(5);           // descent
         if (cur_cost < best_cost) {                                            // algorithms.py:190-191
             best_cost = cur_cost;
@@ -633,14 +639,7 @@ __global__ __launch_bounds__(WPS <= 2 ? 256 : WPS <= 4 ? 1024 : 512, WPS) void g
             A.evals_exec[(size_t)2 * A.B + b] = pert_cycles;
             A.evals_exec[(size_t)3 * A.B + b] = pert_steps;
             A.evals_exec[(size_t)4 * A.B + b] = wall_clock64() - t_start;
-            // ... and of the descent of the outer iterations (wavefront 0; the start descent of algorithms.py:142 is not in it):
-            // total, then per scan kind (two_opt_a2a, relocate_a2a in full, relocate_a2a over flagged rows) count and cycles,
-            // workgroup arg-min (+ waiting for the slowest wavefront), move application + barrier, accepted moves
-            long long *o = A.evals_exec + (size_t)5 * A.B;
-            o[b] = descent_cycles;
-            for (int q = 0; q < 3; ++q) { o[(size_t)(1 + 2 * q) * A.B + b] = dc.scans[q]; o[(size_t)(2 + 2 * q) * A.B + b] = dc.cycles[q]; }
-            o[(size_t)7 * A.B + b] = dc.argmin; o[(size_t)8 * A.B + b] = dc.apply; o[(size_t)9 * A.B + b] = dc.moves;
-            o[(size_t)10 * A.B + b] = 0;
+            // (records 5 .. 14, the cycle account of the descent, were added to in place: DescentCycles)
         }
     } else if (A.evals_exec && tid == 0) {
         // the host only hands this instantiation the buffer when no scan of the run is pruned: executed = reference count
