@@ -368,7 +368,10 @@ __device__ __forceinline__ void assign_waves(const int *len, int R, int nwaves, 
 #define GLS_QUIET_ROWS 1
 #endif
 constexpr double kQuietThr = -2.5e-9;
-constexpr int kQuietPendCap = 5;        // new tour edges between two relocate scans: <= 3 (relocate move) + 2 (2-opt move)
+#ifndef GLS_QUIET_PEND_CAP
+#define GLS_QUIET_PEND_CAP 5            // (test builds set 2: the overflow path -- back to a full scan -- then runs in every descent)
+#endif
+constexpr int kQuietPendCap = GLS_QUIET_PEND_CAP;      // new tour edges between two relocate scans: <= 3 (relocate move) + 2 (2-opt move)
 // LDS of the scheme, in exchange slots the best-improvement descent does not use (bytes 24 .. 119 of Ctl::red_d -- the pruned relocate
 // scan's long-edge list lives there in the 4-slot builds, which do not run this -- and one int of red_k):
 //   words: bit q of word w <-> node 1 + 64 w + q: rows to flag at the next refresh (the full scan's result, the endpoints of new edges)
@@ -379,7 +382,7 @@ struct QuietLds {
     unsigned long long words[2];
     QuietPend pend[kQuietPendCap];
 };
-static_assert(sizeof(QuietLds) == 96, "red_d[0][3] .. red_d[1][6]");
+static_assert(sizeof(QuietLds) <= 96, "red_d[0][3] .. red_d[1][6]");
 __device__ __forceinline__ QuietLds *quiet_lds(Ctl *ctl) { return reinterpret_cast<QuietLds *>(&ctl->red_d[0][3]); }
 __device__ __forceinline__ int *quiet_count(Ctl *ctl) { return &ctl->red_k[0][3]; }
 // start of a descent (thread 0): nothing flagged, nothing pending; every record holds addresses inside the distance triangle
@@ -494,8 +497,9 @@ __device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t,
             hitm0 |= E0 + e < npend ? m : 0ull;
         }
     };
-    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, true);
-    batch(std::integral_constant<int, 3>{}, std::integral_constant<int, kQuietPendCap - 3>{}, false);
+    constexpr int kFirstBatch = kQuietPendCap < 3 ? kQuietPendCap : 3;
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, kFirstBatch>{}, true);
+    if constexpr (kQuietPendCap > 3) batch(std::integral_constant<int, 3>{}, std::integral_constant<int, kQuietPendCap - kFirstBatch>{}, false);
     const bool hit = ((hitm0 >> lane) & 1ull) != 0ull || ((flagword >> ((bc - 1) & 63)) & 1ull) != 0ull;
     if constexpr (CNT) xe += npend * __popcll(__ballot(mine));
     me.act = me.act || (mine && hit);
