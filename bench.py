@@ -249,8 +249,9 @@ def critical_path(n, cyc):
         # three others (the model's constant, stated there)
         desc = cyc["descent_cycles"].sum()
         model = (cp or {}).get("descent", {})
-        kinds = ("two_opt_a2a (pruned scan from n = 80)", "relocate_a2a, every row (first relocate scan of a descent)",
-                 "relocate_a2a, flagged rows only (quiet rows, 80 <= n <= 127)")
+        kinds = ("two_opt_a2a (pruned scan from n = 80)",
+                 "relocate_a2a over every row: the lean scan (for 80 <= n <= 127 only the first relocate scan of a descent), from n = 128 the scan "
+                 "pruned by neighbour lists", "relocate_a2a, flagged rows only (quiet rows, 80 <= n <= 127)")
         keys = ("two_opt", "relocate_full", "relocate_flagged")
         scans = {}
         for q, (name, key) in enumerate(zip(kinds, keys)):
