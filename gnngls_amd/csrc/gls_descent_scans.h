@@ -372,23 +372,30 @@ constexpr double kQuietThr = -2.5e-9;
 #define GLS_QUIET_PEND_CAP 5            // (test builds set 2: the overflow path -- back to a full scan -- then runs in every descent)
 #endif
 constexpr int kQuietPendCap = GLS_QUIET_PEND_CAP;      // new tour edges between two relocate scans: <= 3 (relocate move) + 2 (2-opt move)
-// LDS of the scheme, in exchange slots the best-improvement descent does not use (bytes 24 .. 119 of Ctl::red_d -- the pruned relocate
-// scan's long-edge list lives there in the 4-slot builds, which do not run this -- and one int of red_k):
-//   words: bit q of word w <-> node 1 + 64 w + q: rows to flag at the next refresh (the full scan's result, the endpoints of new edges)
-//   pend:  the new tour edges since the last relocate scan, ready for the refresh (thread 0 does the index arithmetic ONCE per move
-//          instead of every wavefront per refresh): row address terms of x and y for tri_addr_max, the LDS address of D[x,y], 8x | 8y << 16
+// LDS of the scheme, in exchange slots of Ctl the best-improvement descent does not use (its LDS-atomic arg-min takes bytes 0 .. 23 of
+// red_d and the first three ints of red_k; lmax_slot is red_d[1][7]):
+//   words (red_k[0][4] .. red_k[1][3], four 64-bit words): bit q of word w <-> node 1 + 64 w + q: rows to flag at the next refresh
+//          (the full scan's result, the endpoints of new edges)
+//   pend  (red_d[0][4] .. red_d[1][5], five records): the new tour edges since the last relocate scan, ready for the refresh (the
+//          index arithmetic is done ONCE per move, not by every wavefront per refresh): row address terms of x and y for
+//          tri_addr_max, the LDS address of D[x,y], 8x | 8y << 16
+//   count (red_k[0][3])
+// The pruned relocate scan's long-edge list (n >= 128) moved to the remaining slots (16 bytes of red_k, its count to red_d[0][3]).
 struct QuietPend { int xr, yr, laddr, x8y8; };
-struct QuietLds {
-    unsigned long long words[2];
-    QuietPend pend[kQuietPendCap];
-};
-static_assert(sizeof(QuietLds) <= 96, "red_d[0][3] .. red_d[1][6]");
-__device__ __forceinline__ QuietLds *quiet_lds(Ctl *ctl) { return reinterpret_cast<QuietLds *>(&ctl->red_d[0][3]); }
-__device__ __forceinline__ int *quiet_count(Ctl *ctl) { return &ctl->red_k[0][3]; }
+struct QuietLds { unsigned long long *words; QuietPend *pend; int *count; };
+static_assert(kQuietPendCap * sizeof(QuietPend) <= 10 * sizeof(double), "red_d[0][4] .. red_d[1][5]");
+__device__ __forceinline__ QuietLds quiet_lds(Ctl *ctl) {
+    return QuietLds{reinterpret_cast<unsigned long long *>(&ctl->red_k[0][4]), reinterpret_cast<QuietPend *>(&ctl->red_d[0][4]), &ctl->red_k[0][3]};
+}
+__device__ __forceinline__ uint8_t *long_edge_list(Ctl *ctl) { return reinterpret_cast<uint8_t *>(&ctl->red_k[1][4]); }      // 16 positions (n <= 255)
+__device__ __forceinline__ int *long_edge_count(Ctl *ctl) { return reinterpret_cast<int *>(&ctl->red_d[0][3]); }
 // start of a descent (thread 0): nothing flagged, nothing pending; every record holds addresses inside the distance triangle
-__device__ __forceinline__ void quiet_reset(QuietLds *q, int *count, int dbase) {
-    q->words[0] = 0ull; q->words[1] = 0ull; *count = 0;
-    for (int e = 0; e < kQuietPendCap; ++e) q->pend[e] = QuietPend{dbase, dbase, dbase, 0};
+template <int NW>
+__device__ __forceinline__ void quiet_reset(const QuietLds &q, int dbase) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) q.words[w] = 0ull;
+    *q.count = 0;
+    for (int e = 0; e < kQuietPendCap; ++e) q.pend[e] = QuietPend{dbase, dbase, dbase, 0};
 }
 __device__ __forceinline__ void quiet_set(unsigned long long *qmask, int node) {
     typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
@@ -401,7 +408,8 @@ __device__ __forceinline__ void quiet_set(unsigned long long *qmask, int node) {
 //   relocate:      adds (a,c), (d,b), (b,e)                                 (operators.py:76-80, 91-96)
 // Their endpoints are the nodes whose neighbours change: flagged through `words` (LDS atomics: several lanes may hit one word).
 template <class TT>
-__device__ __forceinline__ void quiet_note_move(QuietLds *q, int *count, int dbase, const TT *told, int op, int i, int j, int lane) {
+__device__ __forceinline__ void quiet_note_move(const QuietLds &q, int dbase, const TT *told, int op, int i, int j, int lane) {
+    int *count = q.count;
     const int c0 = *count;                                   // uniform
     const int npairs = op == 0 ? 2 : 3;
     if (lane < npairs && c0 + lane < kQuietPendCap) {
@@ -417,10 +425,10 @@ __device__ __forceinline__ void quiet_note_move(QuietLds *q, int *count, int dba
         }
         const int hi = x > y ? x : y, lo = x > y ? y : x;
         // (x or y may be the depot: kNoRow makes the lane's own row term win in tri_addr_max -- D[b,0] is the first entry of row b)
-        q->pend[c0 + lane] = QuietPend{x == 0 ? kNoRow : dbase + 4 * x * (x - 1), y == 0 ? kNoRow : dbase + 4 * y * (y - 1),
+        q.pend[c0 + lane] = QuietPend{x == 0 ? kNoRow : dbase + 4 * x * (x - 1), y == 0 ? kNoRow : dbase + 4 * y * (y - 1),
                                        dbase + 4 * hi * (hi - 1) + 8 * lo, (8 * x) | ((8 * y) << 16)};
-        if (x >= 1) quiet_set(q->words, x);
-        if (y >= 1) quiet_set(q->words, y);
+        if (x >= 1) quiet_set(q.words, x);
+        if (y >= 1) quiet_set(q.words, y);
     }
     if (lane == 0) *count = c0 + npairs;                     // (> kQuietPendCap cannot happen between two relocate scans; the refresh checks anyway)
 }
@@ -437,24 +445,25 @@ struct QuietLane {
 // lean scan it replaces), so both parts are written for instruction count: pending pairs and the row terms of the uniform node on
 // the scalar unit, packed-triangle addresses in the select-free max form (tri_addr_max), the endpoints of the pending edges as a
 // scalar bit mask, the row constants of a flagged row by v_readlane from the lane that owns its node.
-template <bool CNT, class S, class TT>
+template <bool CNT, int NP, class S, class TT>
 __device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t, const TT *pos, const double *Ef, int n,
-                                                        const QuietLds *q, const int *qcount, QuietLane &me,
+                                                        const QuietLds &q, QuietLane &me,
                                                         int wave, int nwaves, int lane, double &bd, int &bk, int &xe) {
+    // NP = passes of 64 target edges per row = 64-bit flag words: 2 (n <= 127) or 4 (n <= 255)
     const int dbase = lds_byte_addr(s.d);
     ISA_MARK("quiet_refresh_begin");
     // level 0 reads: the pending records and their count, the rows to flag, the lane's node position, the lane's target edges
-    const int npend = __builtin_amdgcn_readfirstlane(*qcount);
+    const int npend = __builtin_amdgcn_readfirstlane(*q.count);
     const int wsh = nwaves == 2 ? 1 : nwaves == 4 ? 2 : nwaves == 8 ? 3 : 4;      // log2(nwaves): 2 .. 16 wavefronts
     const int b = 1 + (lane << wsh) + wave;                  // lane l <-> node b = 1 + nwaves l + wave
     const bool mine = b <= n - 1;
     const int bc = mine ? b : 1;
     const int i = pos[bc];
-    const unsigned long long flagword = q->words[(bc - 1) >> 6];
-    int dnode[2], enode[2];
-    double len[2];
+    const unsigned long long flagword = q.words[(bc - 1) >> 6];
+    int dnode[NP], enode[NP];
+    double len[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int k = lane + p * kWave;
         const bool ok = k <= n - 1;
         const int kc = ok ? k : 0;
@@ -476,7 +485,7 @@ __device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t,
         double lxy[EN], dxb[EN], dby[EN];
 #pragma unroll
         for (int e = 0; e < EN; ++e) {
-            const int4 rec = *reinterpret_cast<const int4 *>(&q->pend[E0 + e]);      // uniform address
+            const int4 rec = *reinterpret_cast<const int4 *>(&q.pend[E0 + e]);       // uniform address
             const int x8 = rec.w & 0xffff, y8 = (int)((unsigned)rec.w >> 16);
             lxy[e] = lds_read_f64(rec.z);
             dxb[e] = lds_read_f64(tri_addr_max(bXl, b8l, rec.x, x8));
@@ -505,21 +514,20 @@ __device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t,
     me.act = me.act || (mine && hit);
     ISA_MARK("quiet_refresh_end");
 
-    // ---- reduced scan: lane l holds target edges k = l and l + 64 -- (d, e) = (t[k], t[k+1]) with their packed row addresses
-    // and D[d,e] in registers --; a row is two passes of two random LDS reads, three fp64 adds, two compares ----
+    // ---- reduced scan: lane l holds target edges k = l + 64 p -- (d, e) = (t[k], t[k+1]) with their packed row addresses and
+    // D[d,e] in registers --; a row is NP passes of two random LDS reads, three fp64 adds, two compares ----
     unsigned long long rows = __ballot(me.act);
     if (!rows) return true;
-    int dx[2], d8[2], ex[2], e8[2];
+    int dx[NP], d8[NP], ex[NP], e8[NP];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
         const int d = dnode[p], e = enode[p];
         // tri_addr_max: the depot (position 0 / n only) passes kNoRow so that the row's own address term wins
         dx[p] = opaque_vgpr(d == 0 ? kNoRow : dbase + 4 * d * (d - 1)); d8[p] = opaque_vgpr(8 * d);
         ex[p] = opaque_vgpr(e == 0 ? kNoRow : dbase + 4 * e * (e - 1)); e8[p] = opaque_vgpr(8 * e);
     }
-    const int live1 = n - kWave > 0 ? n - kWave : 0;         // live lanes of the second pass (k = 64 .. n-1)
     const long long basebits = __double_as_longlong(base);
-    const int klane1 = lane + 1;                             // k - i + 1 = klane1 - i for the first pass, + 64 for the second
+    const int klane1 = lane + 1;                             // k - i + 1 = klane1 - i for the first pass, + 64 p for pass p
     unsigned long long quiet = 0ull;                         // rows found quiet
     ISA_MARK("quiet_row_loop");
     while (rows) {
@@ -530,32 +538,36 @@ __device__ __forceinline__ bool scan_relocate_a2a_quiet(const S &s, const TT *t,
         const int bX = __builtin_amdgcn_readlane(bXl, l), b8 = __builtin_amdgcn_readlane(b8l, l);
         const double rbase = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(basebits >> 32), l) << 32) |
                                                   (unsigned)__builtin_amdgcn_readlane((int)basebits, l));
-        const double vd0 = lds_read_f64(tri_addr_max(dx[0], d8[0], bX, b8));      // D[d,b]  (garbage on the lanes k in {i-1, i}: masked below)
-        const double ve0 = lds_read_f64(tri_addr_max(ex[0], e8[0], bX, b8));      // D[b,e]
-        const double vd1 = lds_read_f64(tri_addr_max(dx[1], d8[1], bX, b8));      // (second pass: dead lanes read a valid address, their delta is +inf)
-        const double ve1 = lds_read_f64(tri_addr_max(ex[1], e8[1], bX, b8));
-        double delta0 = rbase - len[0];                      // -D[d,e]          (operators.py:100-102, left to right)
-        delta0 = delta0 + vd0;                               // +D[d,b]
-        delta0 = delta0 + ve0;                               // +D[b,e]
-        double delta1 = rbase - len[1];
-        delta1 = delta1 + vd1;
-        delta1 = delta1 + ve1;
-        // quiet test: every target edge but the row's own two, k in {i-1, i}  <=>  (unsigned)(k - i + 1) < 2
-        const unsigned u0 = (unsigned)(klane1 - ri);
-        const unsigned long long own0 = __ballot(u0 < 2u), own1 = __ballot(u0 + (unsigned)kWave < 2u);
-        const unsigned long long hitm = (__ballot(delta0 < kQuietThr) & ~own0) | (__ballot(delta1 < kQuietThr) & ~own1);
-        if constexpr (CNT) xe += (n < kWave ? n : kWave) + live1;
-        if (min_f64_raw(delta0, delta1) <= bd) {
+        double vd[NP], ve[NP], delta[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {                       // (dead lanes read a valid address, their delta is +inf)
+            vd[p] = lds_read_f64(tri_addr_max(dx[p], d8[p], bX, b8));       // D[d,b]  (garbage on the lanes k in {i-1, i}: masked below)
+            ve[p] = lds_read_f64(tri_addr_max(ex[p], e8[p], bX, b8));       // D[b,e]
+        }
+        const unsigned u0 = (unsigned)(klane1 - ri);         // quiet test: every target edge but the row's own two, (unsigned)(k - i + 1) < 2
+        unsigned long long hitm = 0ull;
+        double dmin = __builtin_inf();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            double d = rbase - len[p];                       // -D[d,e]          (operators.py:100-102, left to right)
+            d = d + vd[p];                                   // +D[d,b]
+            d = d + ve[p];                                   // +D[b,e]
+            delta[p] = d;
+            hitm |= __ballot(d < kQuietThr) & ~__ballot(u0 + (unsigned)(p * kWave) < 2u);
+            dmin = p == 0 ? d : min_f64_raw(dmin, d);
+        }
+        if constexpr (CNT) xe += n;
+        if (dmin <= bd) {
             rare_path();
             ISA_MARK("quiet_row_rare");
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const double delta = p ? delta1 : delta0;
+            for (int p = 0; p < NP; ++p) {
+                const double d = delta[p];
                 const int kk = lane + p * kWave;
                 // valid targets: k not in {i-2, i-1, i} (operators.py:133-136: i - j == 1 <=> k = i - 2)
-                if (delta <= bd && (unsigned)(kk - ri + 2) > 2u && !close_to_zero(delta)) {
+                if (d <= bd && (unsigned)(kk - ri + 2) > 2u && !close_to_zero(d)) {
                     const int key = make_key(ri, kk < ri ? kk + 1 : kk);
-                    if (delta < bd || key < bk) { bd = delta; bk = key; }
+                    if (d < bd || key < bk) { bd = d; bk = key; }
                 }
             }
         }
@@ -985,12 +997,15 @@ __device__ __forceinline__ void scan_two_opt_a2a_pruned(const S &s, const TT *t,
     }
 }
 
-template <bool CNT, class S, class TT>
+// QT (quiet rows, see scan_relocate_a2a_quiet): also flag, in qwords, every row with an evaluated candidate below the quiet threshold.
+// A candidate this scan prunes away has delta >= 0 (the argument above), so a row it does not flag is quiet; the candidate the
+// reference skips for orientation (k = p - 2) is evaluated for the flag, never considered as a move.
+template <bool CNT, bool QT, class S, class TT>
 __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t, const TT *pos, const double *Ef,
                                                          const NlWords &nlw, int n, double Lcap,
-                                                         const int *longk, int nlong,
+                                                         const uint8_t *longk, int nlong,
                                                          int tid, int nthr, int lane, double &bd, int &bk, int &xe,
-                                                         long long *dbg = nullptr) {
+                                                         long long *dbg = nullptr, unsigned long long *qwords = nullptr) {
     const PlainDist<S> f{s};
     const int tasks = 8 * (n - 1);
     const int rowbit = (lane & 56) + 7;
@@ -1012,17 +1027,21 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
         // row evaluates them directly: a single long edge left by the perturbation phase would otherwise push every row's
         // threshold beyond its list (12.9 of 16 rows per wavefront overflowed with the tour's maximum edge as the bound).
         const double Tmax = Lcap - base;
+        bool qhit = false;                                       // QT: an evaluated candidate of this lane's row is below the quiet threshold
+        // targets evaluated: k not in {p-1, p} with QT (the row's own two edges), k not in {p-2, p-1, p} else
+        auto target_ok = [&](int k) { return QT ? (unsigned)(k - p + 1) > 1u : (unsigned)(k - p + 2) > 2u; };
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bool lk = live && m + 8 * u < nlong;
-            const int k = lk ? longk[m + 8 * u] : p;             // (k = p is never a valid target)
-            const bool ev = (unsigned)(k - p + 2) > 2u;
+            const int k = lk ? (int)longk[m + 8 * u] : p;        // (k = p is never a valid target)
+            const bool ev = target_ok(k);
             if constexpr (CNT) xe += __popcll(__ballot(ev));
             if (ev) {
                 double delta = base - Ef[k + 1];                 // operators.py:100-102, left to right
                 delta = delta + s.dist(t[k], b);                 // +D[d,b]
                 delta = delta + s.dist(b, t[k + 1]);             // +D[b,e]
-                consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
+                if (QT) qhit = qhit || delta < kQuietThr;
+                if (!QT || k != p - 2) consider<false>(delta, make_key(p, k < p ? k + 1 : k), bd, bk);
             }
         }
         bool more = live;
@@ -1042,20 +1061,22 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
                 const double two_d = d + d;
                 const bool act = more && two_d < Tmax;
                 // valid targets of row p: k not in {p-2, p-1, p} (operators.py:133-136: i - j == 1 <=> k = p - 2)
-                const bool c1 = act && (unsigned)(k1 - p + 2) > 2u && two_d < e1 - base;
-                const bool c2 = act && (unsigned)(k2 - p + 2) > 2u && two_d < e2 - base;
+                const bool c1 = act && target_ok(k1) && two_d < e1 - base;
+                const bool c2 = act && target_ok(k2) && two_d < e2 - base;
                 if constexpr (CNT) xe += __popcll(__ballot(c1)) + __popcll(__ballot(c2));
                 if (c1) {
                     double delta = base - e1;                    // operators.py:100-102, left to right
                     delta = delta + d;                           // +D[d,b]
                     delta = delta + s.dist(b, t[k1 + 1]);        // +D[b,e]
-                    consider<false>(delta, make_key(p, k1 < p ? k1 + 1 : k1), bd, bk);
+                    if (QT) qhit = qhit || delta < kQuietThr;
+                    if (!QT || k1 != p - 2) consider<false>(delta, make_key(p, k1 < p ? k1 + 1 : k1), bd, bk);
                 }
                 if (c2) {
                     double delta = base - e2;
                     delta = delta + s.dist(t[k2], b);            // +D[d,b]
                     delta = delta + d;                           // +D[b,e]
-                    consider<false>(delta, make_key(p, k2 < p ? k2 + 1 : k2), bd, bk);
+                    if (QT) qhit = qhit || delta < kQuietThr;
+                    if (!QT || k2 != p - 2) consider<false>(delta, make_key(p, k2 < p ? k2 + 1 : k2), bd, bk);
                 }
                 if (u == 1) last = act;
             }
@@ -1072,11 +1093,16 @@ __device__ __forceinline__ void scan_relocate_a2a_pruned(const S &s, const TT *t
             om &= om - 1;
             const int pr = __builtin_amdgcn_readlane(p, src);
             if constexpr (CNT) xe += n - 2 - (pr > 1 ? 1 : 0);
+            bool rhit = false;
             for (int j = 1 + lane; j <= n - 1; j += kWave) {
-                if (j == pr || pr - j == 1) continue;
-                consider<false>(relocate_cost(t, f, pr, j), make_key(pr, j), bd, bk);
+                if (j == pr || (!QT && pr - j == 1)) continue;
+                const double delta = relocate_cost(t, f, pr, j);
+                if (QT) rhit = rhit || delta < kQuietThr;
+                if (!QT || pr - j != 1) consider<false>(delta, make_key(pr, j), bd, bk);
             }
+            if (QT && rhit) quiet_set(qwords, (int)t[pr]);       // (pr >= 1: never the depot)
         }
+        if (QT && qhit && live) quiet_set(qwords, b);
     }
 }
 

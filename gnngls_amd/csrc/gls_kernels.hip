@@ -138,8 +138,8 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             }
         }
     }
-    if constexpr (GLS_QUIET_ROWS && kCanPrune && GP == 2 && WPS <= 4) {
-        if (prune && tid == 0) quiet_reset(quiet_lds(ctl), quiet_count(ctl), lds_byte_addr(s.d));
+    if constexpr (GLS_QUIET_ROWS && kCanPrune && (GP == 2 || (GP == 4 && S::kPenInLds)) && WPS <= 4) {
+        if (prune && tid == 0) quiet_reset<GP>(quiet_lds(ctl), lds_byte_addr(s.d));
     }
     __syncthreads();
     if (prune) Lmax = unsortable(*lmax_slot(ctl));
@@ -147,15 +147,21 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
     // listed per scan (at most kLongCap, else that scan runs unpruned) in exchange slots the descent does not use
     constexpr int kLongCap = 16;
     const double Lcap = GLS_LCAP_FACTOR * cur_cost / (double)n;
-    int *longk = reinterpret_cast<int *>(&ctl->red_d[0][3]);     // 16 ints: bytes 24 .. 87 of red_d
-    int *nlong_slot = &ctl->red_k[1][0];
+    uint8_t *longk = long_edge_list(ctl);                        // 16 positions (n <= 255), see QuietLds for the layout of the slots
+    int *nlong_slot = long_edge_count(ctl);
     (void)Lmax;
     // quiet rows of the relocate scan (gls_descent_scans.h): the two-slot builds with neighbour lists on, i.e. 80 <= n <= 127 on the
     // lean relocate scan; the first relocate scan of a descent is the full one and sets the bits
-    constexpr bool kQuietRows = GLS_QUIET_ROWS && kCanPrune && GP == 2 && WPS <= 4;
-    const bool quiet = kQuietRows && prune && nwaves >= 2 && (nwaves & (nwaves - 1)) == 0 && n <= GP * kWave - 1;
-    QuietLds *ql = quiet_lds(ctl);
-    int *qcount = quiet_count(ctl);
+    // four-slot builds: the LDS-penalty store only (n = 128 .. 163 at one instance per CU, 8 wavefronts: +6 .. +13 %); in the compact
+    // store's four-slot instantiation -- TSP200 on 16 wavefronts, where the scheme does not pay -- the code's mere presence cost 2.8 %
+    // (scratch 88 -> 104 B), so it is compiled out there
+    constexpr bool kQuietRows = GLS_QUIET_ROWS && kCanPrune && (GP == 2 || (GP == 4 && S::kPenInLds)) && WPS <= 4;
+    // (with 16 wavefronts per instance -- the compact store from n = 144 up: TSP200 -- every wavefront pays the refresh for 13 nodes and the
+    // pruned relocate scan it replaces is only 1.55 passes: measured -1 .. -2 % at n = 170 .. 200, +6 % (model guide) / +12 % (noise) at
+    // n = 140 .. 160 on 8 wavefronts, profiles/r06_experiments/ab_quiet_rows_gp4*.log)
+    const bool quiet = kQuietRows && prune && nwaves >= 2 && (nwaves & (nwaves - 1)) == 0 && n <= GP * kWave - 1 && n - 1 <= nwaves * kWave &&
+                       (GP == 2 || nwaves <= 8);
+    const QuietLds ql = quiet_lds(ctl);
     QuietLane qme{false};
     bool have_bits = false;
     bool improved = true;
@@ -170,14 +176,14 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             int xs = 0;          // evaluations this wavefront executes in a pruned scan (scalar; booked once per scan below)
             if constexpr (kCanPrune) {
                 int nlong = 0;
-                if (kPruneRelocate && prune && op == 1) {
+                if (kPruneRelocate && prune && op == 1 && !(kQuietRows && quiet && have_bits)) {      // (a flagged-rows scan needs no long-edge list)
                     if (tid == 0) *nlong_slot = 0;
                     __syncthreads();
                     for (int q = 1 + tid; q <= n; q += nthr)
                         if (Ef[q] > Lcap) {
                             typedef __attribute__((address_space(3))) int lds_i32_t;
                             const int slot = __hip_atomic_fetch_add((lds_i32_t *)nlong_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (slot < kLongCap) longk[slot] = q - 1;            // target edge k = (t[k], t[k+1]), Ef[k+1] its length
+                            if (slot < kLongCap) longk[slot] = (uint8_t)(q - 1); // target edge k = (t[k], t[k+1]), Ef[k+1] its length
                         }
                     __syncthreads();
                     nlong = *nlong_slot;
@@ -192,9 +198,18 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                     long long *dbg = nullptr;
 #endif
                     if (op == 0) scan_two_opt_a2a_pruned<CNT, S, TT>(s, t, ppos, Ef, pc.nlw, n, tid, nthr, lane, bd, bk, xs, dbg);
-                    else if constexpr (kPruneRelocate)
-                        scan_relocate_a2a_pruned<CNT, S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, xs, dbg);
-                    lean = true; pruned_scan = true;
+                    else if constexpr (kPruneRelocate) {
+                        if (kQuietRows && quiet && have_bits) {
+                            // (n >= 128: the flagged-rows scan below takes this relocate scan; the list walk only runs for the first of a descent)
+                        } else if (kQuietRows && quiet) {
+                            scan_relocate_a2a_pruned<CNT, kQuietRows, S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, xs, dbg, ql.words);
+                            have_bits = true; lean = true; pruned_scan = true;
+                        } else {
+                            scan_relocate_a2a_pruned<CNT, false, S, TT>(s, t, ppos, Ef, pc.nlw, n, Lcap, longk, nlong, tid, nthr, lane, bd, bk, xs, dbg);
+                            lean = true; pruned_scan = true;
+                        }
+                    }
+                    if (op == 0) { lean = true; pruned_scan = true; }
                 }
             }
             // measured (outer iterations per instance): TSP50 7.2k -> 8.2k, TSP100 9.9k -> 10.4k, TSP200 3.8k -> 3.6k;
@@ -213,7 +228,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
 #ifdef GLS_STAMPS
                         const long long q0 = clock64();
 #endif
-                        const bool ok = scan_relocate_a2a_quiet<CNT, S, TT>(s, t, ppos, Ef, n, ql, qcount, qme, wave_u, nwaves, lane, bd, bk, xs);
+                        const bool ok = scan_relocate_a2a_quiet<CNT, GP, S, TT>(s, t, ppos, Ef, n, ql, qme, wave_u, nwaves, lane, bd, bk, xs);
                         if (ok) {
 #ifdef GLS_STAMPS
                             st.acc[20] += 1; st.acc[21] += clock64() - q0; st.acc[23] += __popcll(__ballot(qme.act));
@@ -222,7 +237,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                         } else {                                     // pending list overflow (cannot happen): start over with a full scan
                             have_bits = false; qme.act = false;
                             __syncthreads();
-                            if (tid == 0) quiet_reset(ql, qcount, lds_byte_addr(s.d));
+                            if (tid == 0) quiet_reset<GP>(ql, lds_byte_addr(s.d));
                             __syncthreads();
                         }
                     }
@@ -233,7 +248,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                     constexpr int kUR = (WPS <= 4 && GP == 2) ? GLS_LEAN_UNROLL_RELOCATE : GLS_LEAN_UNROLL;
                     if (op == 0) scan_two_opt_a2a_lean<GP, kMF, S, TT>(s, t, Eb, n, wave, nwaves, lane, bd, bk);
                     else if (kQuietRows && quiet) {
-                        scan_relocate_a2a_lean<GP, kMF, kUR, S, TT, kQuietRows>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos, ql->words);
+                        scan_relocate_a2a_lean<GP, kMF, kUR, S, TT, kQuietRows>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos, ql.words);
                         have_bits = true;
                     }
                     else         scan_relocate_a2a_lean<GP, kMF, kUR, S, TT>(s, t, Ef, n, wave, nwaves, lane, bd, bk, pos);
@@ -264,7 +279,11 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
             if constexpr (kQuietRows) {
                 // every wavefront has consumed the pending records and the rows to flag (two barriers ago at least): the wavefront that
                 // notes the moves (the last one) clears them, in program order before it notes this scan's own move
-                if (quiet_scan && wave_u == nwaves - 1 && lane == 0) { ql->words[0] = 0ull; ql->words[1] = 0ull; *qcount = 0; }
+                if (quiet_scan && wave_u == nwaves - 1 && lane == 0) {
+#pragma unroll
+                    for (int w = 0; w < GP; ++w) ql.words[w] = 0ull;
+                    *ql.count = 0;
+                }
             }
             STAMP_END(9);    // wave + workgroup arg-min (includes waiting for the slowest wave)
             STAMP_COUNT(11);
@@ -280,7 +299,7 @@ __device__ __forceinline__ void local_search_dev(const S &s, TT *&t, TT *&t2, do
                 apply_move(s, t, t2, Ef, Eb, n, op, bk >> 16, bk & 0xffff, tid, nthr, true, pos, prune ? ppos : nullptr, ctl, Lmax);
                 if constexpr (kQuietRows) {
                     // the move's new tour edges go to the pending list of the next relocate scan's refresh (from the OLD tour)
-                    if (quiet && have_bits && wave_u == nwaves - 1) quiet_note_move(ql, qcount, lds_byte_addr(s.d), t, op, bk >> 16, bk & 0xffff, lane);
+                    if (quiet && have_bits && wave_u == nwaves - 1) quiet_note_move(ql, lds_byte_addr(s.d), t, op, bk >> 16, bk & 0xffff, lane);
                 }
                 TT *x = t; t = t2; t2 = x;
                 if (tid == 0) tr.push(cur_cost);
