@@ -60,6 +60,15 @@ for _k in ["nonmetric", "negative", "huge"] * 4:
                       seed=int(_rng3.integers(1 << 30))))
 
 
+# round 6: the quiet rows of the relocate scan (exact don't-look flags: 80 <= n <= 127 on every symmetric store, 128 <= n <= 163 on
+# the LDS-penalty store) over several outer iterations, on matrices full of exact ties and of deltas around np.isclose's threshold
+_rng4 = np.random.default_rng(97531)
+for _k in ["lattice", "noisy", "euclid", "nonmetric"] * 3:
+    CASES.append(dict(n=int(_rng4.integers(80, 164)), kind=_k, pm=int(_rng4.choice([5, 20])), fi=False,
+                      K=int(_rng4.integers(4, 9)), bits=int(_rng4.choice([0, 0, -2])), guides=int(_rng4.integers(1, 3)),
+                      seed=int(_rng4.integers(1 << 30))))
+
+
 VARIANTS = {"serial": (0, 1), "team": (1, 1), "fullscan": (0, 0)}     # (team form of the perturbation phase, pruned descent scans)
 
 
