@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Can the GNN forward of the NEXT device load run under the search of the current one?  (round-5 review, item 5b)
 
-The search kernel's workgroups hold 40 KB of LDS each for the whole search; every forward kernel needs 57-142 KB per workgroup.
-This probe launches a 2 s search of R resident instances on one stream and, on a second stream, forward passes of 1,024 instances
-(GNNGLS_FFN_FP32=1: the fp32 feed-forward block, 74 KB per workgroup, is the only one that fits beside two search workgroups per CU),
-and reports what each side got done alone and together.
+The search kernel's workgroups hold 40 KB of LDS and 4 wavefronts x 128 VGPRs each for the whole search (compact store, forced
+here for every R); `gat_rows` needs 70 KB per workgroup, the feed-forward block 142 KB (GNNGLS_FFN_FP32=1: the fp32 form, 74 KB, the
+only one that fits beside two search workgroups per CU).  This probe launches a 2 s search of R resident instances on one stream
+and, on a second stream, forward passes of 1,024 instances, and reports what each side got done alone and together.
 
     GNNGLS_FFN_FP32=1 python scripts/probe_overlap.py            (on an MI355X)
 """
@@ -31,7 +31,8 @@ def search(B, stream):
     with torch.cuda.stream(stream):
         D, g = Dall[:B].contiguous(), R[:B][None].contiguous()
         init = ops.nearest_neighbor(R[:B].contiguous()); cost = ops.tour_cost(init, D)
-        return ops.gls_run(D, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=T)
+        return ops.gls_run(D, g, init, cost, perturbation_moves=20, max_outer_iters=-1, time_limit_s=T,
+                           penalty_bits=-2)      # the compact store at every R: 40 KB of LDS, 4 wavefronts at 128 VGPRs per instance
 
 
 def forwards(stream, seconds):
@@ -44,10 +45,11 @@ def forwards(stream, seconds):
     return done, time.time() - t0
 
 
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+# --priority: the forward stream at high priority (a hardware queue of its own)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1 if "--priority" in sys.argv else 0)
 k, dt = forwards(s2, 1.0)
 print(f"forward alone: {dt / k * 1e3:.1f} ms per 1,024 instances")
-for B in (1024, 768, 512):
+for B in (1024, 768, 512, 256, 128):    # search workgroups per CU: 4, 3, 2, 1, one on every other CU
     r = search(B, s1); s1.synchronize()
     alone = float(r.outer_iters.double().mean())
     torch.cuda.synchronize()
