@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 // model of both paths: 4.5e-7 against 4.8e-7 of max|y|; three products, i.e. two pieces, would be 6.5e-6).  Inference only; the
 // training kernels above stay on the fp32 pipe.
 // The weights are split and laid out in fragment order by ffn_pack_bf16x3_kernel, once per weight image (gnngls_regret_prepare; 786 KB per layer):
-//     W1p[c][kb][ht][p][lane][8]   = piece p of W1[128 c + 16 ht + (lane & 15)][32 kb + 8 (lane >> 4) + e]
+//     W1p[c][kb][ht][p][lane][8]   = piece p of W1[128 c + 16 ht + (lane & 15)][32 kb + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
 //     W2p[c][j][ot][p][lane][8]    = piece p of W2[16 ot + (lane & 15)][128 c + 32 j + 16 (e >> 2) + 4 (lane >> 4) + (e & 3)]
 // so that a stage's 24 KB are a flat copy into LDS and a wavefront's A fragment is one conflict-free ds_read_b128.  The k order of
 // W2p is the accumulator layout of GEMM1 (lane (row, q) holds hidden units 16 ht + 4 q + r of its row): as in the fp32 kernel
@@ -831,7 +831,7 @@ __global__ void ffn_pack_bf16x3_kernel(const float *__restrict__ W1, const float
 #pragma unroll
     for (int e = 0; e < 8; ++e)
         v[e] = second ? W2[(long)(tile * 16 + lr) * 512 + c * 128 + 32 * sub + 16 * (e >> 2) + 4 * lq + (e & 3)]
-                      : W1[(long)(c * 128 + tile * 16 + lr) * 128 + 32 * sub + 8 * lq + e];
+                      : W1[(long)(c * 128 + tile * 16 + lr) * 128 + 32 * sub + 16 * (e >> 2) + 4 * lq + (e & 3)];
     bf16x8 p0, p1, p2;
     split_bf16x3(v, p0, p1, p2);
     unsigned char *dst = packed + (size_t)second * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE + (size_t)(tile * 3) * 1024 + lane * 16;
@@ -945,11 +945,15 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
 
     bf16x8 q0, q1, q2;                                   // B pieces of the current stage
     bf16x8 fa0, fa1, fa2;                                // A fragments of the current stage's first tile
-    auto x_values = [&](int kb, float (&v)[8]) {         // GEMM1, k block kb: x[row][32 kb + 8 q .. + 7]
-        const float *xp = Xs + (wrow + lr) * LDX + kb * 32 + 8 * lq;
-        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+    // The wavefront's x rows in the accumulator layout, in registers for the whole block: lane (row, q) holds columns 16 ot + 4 q + r.
+    // W1p's k order is that layout (as W2p's is for the hidden layer), so xa is the B operand of GEMM1 AND the skip connection of the
+    // epilogue; the x tile in LDS is only the staging area of the prologue's coalesced loads.
+    f32x4 xa[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+    for (int ot = 0; ot < 8; ++ot) xa[ot] = *reinterpret_cast<const f32x4 *>(Xs + (wrow + lr) * LDX + ot * 16 + 4 * lq);
+    auto x_values = [&](int kb, float (&v)[8]) {         // GEMM1, k block kb: columns 32 kb + 16 (e >> 2) + 4 q + (e & 3)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = xa[2 * kb][e]; v[4 + e] = xa[2 * kb + 1][e]; }
     };
     bf16x8 fb0, fb1, fb2;                                // ... and of its second tile (fragments are read two tiles ahead: one tile's
                                                          // six MFMAs, 96 cycles, do not cover an LDS round trip with eight wavefronts reading)
@@ -1038,12 +1042,14 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         }
     }
 
-    // ---- epilogue: y = BN2(x + (acc + b2)); transposed accumulator -> x tile in LDS -> coalesced rows ----
+    // ---- epilogue: y = BN2(x + (acc + b2)), stored from the accumulator layout: a lane's four columns of a 16-column tile are one
+    // 16-byte store, the eight tiles of a row complete its 512 bytes in L2 ----
+    const long mrow = row0 + wrow + lr;
+    const bool rlive = mrow < M && (!(FFN_DBG & 2) || mrow == 0);
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) {
         const int out = ot * 16 + 4 * lq;
-        float *xp = Xs + (wrow + lr) * LDX + out;
-        f32x4 x = *reinterpret_cast<const f32x4 *>(xp);
+        f32x4 x = xa[ot];
         const f32x4 bb = *reinterpret_cast<const f32x4 *>(vecs + 512 + out);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(vecs + 640 + out);
         const f32x4 sh = *reinterpret_cast<const f32x4 *>(vecs + 768 + out);
@@ -1053,17 +1059,9 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             v = x[r] + v;                             // x + y            (models.py:15)
             x[r] = v * sc[r] + sh[r];                 // BatchNorm1d eval (models.py:35)
         }
-        *reinterpret_cast<f32x4 *>(xp) = x;
+        if (rlive) *reinterpret_cast<f32x4 *>(hout + mrow * kD + out) = x;
         accH[ot] = x;                                 // (the layer's output in the accumulator layout: the B operand of the fc stages)
     }
-    auto store_tile = [&](float *dst) {               // the tile in Xs, coalesced rows
-        for (int it = 0; it < (FB_M * 32) / 512; ++it) {
-            const int idx = it * 512 + tid;
-            const int row = idx >> 5, c = (idx & 31) * 4;
-            const long m = row0 + row;
-            if (m < M && (!(FFN_DBG & 2) || m == 0)) *reinterpret_cast<f32x4 *>(dst + m * kD + c) = *reinterpret_cast<const f32x4 *>(Xs + row * LDX + c);
-        }
-    };
     if (packed_fc) {
         // ---- the next layer's ft = fc(h) chained from the registers exactly as GEMM2 is chained from GEMM1: lane (row, q) holds outputs
         // 16 ot + 4 q + r of its row, which is the k order the packed fc weights are laid out in (ffn_pack_fc_bf16x3_kernel) ----
@@ -1096,15 +1094,10 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             __syncthreads();
             rb = rb1;
         }
-        store_tile(hout);                             // (the barriers of the fc stages lie between the tile's writes and these reads)
-        __syncthreads();
+        if (rlive) {
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot) *reinterpret_cast<f32x4 *>(Xs + (wrow + lr) * LDX + ot * 16 + 4 * lq) = accY[ot];
-        __syncthreads();
-        store_tile(ft_out);
-    } else {
-        __syncthreads();
-        store_tile(hout);
+            for (int ot = 0; ot < 8; ++ot) *reinterpret_cast<f32x4 *>(ft_out + mrow * kD + ot * 16 + 4 * lq) = accY[ot];
+        }
     }
 }
 
