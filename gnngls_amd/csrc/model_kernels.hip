@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 // 8.2 ms per launch including the fc against 11.2 + 1.8 ms of the fp32 kernels, 180 fp32-equivalent TFLOP/s; matrix pipe 50 % busy.
 // ---------------------------------------------------------------------------------------------
 #ifndef FFN_DBG
-#define FFN_DBG 0                    // bits: 1 no main loop, 2 no HBM traffic in the prologue / epilogue, 4 no weight streaming, 8 no MFMAs (time attribution builds)
+#define FFN_DBG 0                    // bits: 1 no main loop, 2 no HBM traffic in the prologue / epilogue, 4 no weight streaming, 8 no MFMAs, 16 no fragment reads, 32 no operand split (time attribution builds)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int FB_M = 128;                          // rows per workgroup
@@ -975,12 +975,15 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
 #pragma unroll
         for (int tl = 0; tl < 8; ++tl) {
             const unsigned char *f = (tl < 6 ? Wt + (size_t)((tl + 2) * 3) * 1024 : Wnext + (size_t)((tl - 6) * 3) * 1024) + lane * 16;
-            const bf16x8 m0 = *reinterpret_cast<const bf16x8 *>(f);
-            const bf16x8 m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
-            const bf16x8 m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+            bf16x8 m0 = a0, m1 = a1, m2 = a2;
+            if (!(FFN_DBG & 16)) {
+                m0 = *reinterpret_cast<const bf16x8 *>(f);
+                m1 = *reinterpret_cast<const bf16x8 *>(f + 1024);
+                m2 = *reinterpret_cast<const bf16x8 *>(f + 2048);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (!(FFN_DBG & 8)) acc[tl] = mfma_bf16x3(a0, a1, a2, q0, q1, q2, acc[tl]);
-            if (tl >= 3 && tl < 7) slice(tl - 3);
+            if (tl >= 3 && tl < 7 && !(FFN_DBG & 32)) slice(tl - 3);
             __builtin_amdgcn_sched_barrier(0);
             a0 = b0; a1 = b1; a2 = b2;
             b0 = m0; b1 = m1; b2 = m2;
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             float v[8];
             if (sub < 3) x_values(sub + 1, v);
             else if (sub == 7) x_values(0, v);
-            bf16x8 n0, n1, n2;
+            bf16x8 n0 = q0, n1 = q1, n2 = q2;            // (attribution builds without the split keep the last operand)
             auto slice = [&](int k) {                    // elements 2 k, 2 k + 1
                 if (sub >= 3 && sub < 7) {
                     const int j = sub - 3, hh = k >> 1, e0 = 2 * (k & 1);
