@@ -496,15 +496,19 @@ __device__ __forceinline__ void pin(PairLoad &g) { asm volatile("" : "+v"(g.p), 
 // (counter, distance, guide) of every tour edge, and the row offsets of its nodes, from E.u / E.v
 template <class S, int GP>
 __device__ __forceinline__ void edges_fetch(const S &s, TourEdges<GP> &E, const double *guide, int n) {
+    // counters and distances first, the guide values (the farthest memory: 80 KB per TSP100 instance, read once per edge) last: loads
+    // return in order, and the scan that follows a move needs the former, only the next arg-max the latter (round 6: +2.5 % outer
+    // iterations at TSP100 x 1024, +1 % at TSP200 x 256, profiles/r06_experiments/ab_duo4.log, variants _duo0 / _gl0)
 #pragma unroll
     for (int q = 0; q < GP; ++q) {
         const int u = E.u[q], v = E.v[q];
-        E.gq[q] = guide[(unsigned)(u * n + v)];
         E.ur[q] = 2 * __mul24(u, u - 1); E.vr[q] = 2 * __mul24(v, v - 1);
         const int off = sel_b32(__builtin_amdgcn_ballot_w64(v > u), E.vr[q] + 4 * u, E.ur[q] + 4 * v);
         E.pq[q] = s.pen_at_byte(off);
         E.de[q] = s.dist_at_byte(2 * off);
     }
+#pragma unroll
+    for (int q = 0; q < GP; ++q) E.gq[q] = guide[(unsigned)(E.u[q] * n + E.v[q])];
 }
 template <class S, int GP, class TT>
 __device__ __forceinline__ void edges_load(const S &s, TourEdges<GP> &E, const TT *t, const double *guide, int n, int lane) {
