@@ -394,7 +394,8 @@ int64_t gnngls_regret_forward_workspace_bytes(int B, int n) {
 
 int64_t gnngls_regret_prepared_bytes(int n_layers) {
     if (n_layers < 0) return 0;
-    return (int64_t)n_layers * (int64_t)gnngls::ffn_packed_bytes() + 256;
+    // per layer the feed-forward weights in bf16 pieces; behind them A = We^T Wfc^T and b' = Wfc be of the fused embed + first fc
+    return (int64_t)n_layers * (int64_t)gnngls::ffn_packed_bytes() + (int64_t)gnngls::embed_fc_bytes() + 256;
 }
 
 int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *prepared, int64_t prepared_bytes, void *stream) {
@@ -409,6 +410,11 @@ int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *
         const float *w1 = w + 128L * 128 + 4 * 128, *w2 = w1 + 512L * 128 + 512;
         const float *fc_next = l + 1 < n_layers ? layers + (long)(l + 1) * kLayerFloats : nullptr;
         hipError_t e = gnngls::launch_ffn_pack(w1, w2, fc_next, base + (size_t)l * gnngls::ffn_packed_bytes(), (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "regret_prepare");
+    }
+    if (n_layers > 0 && in_dim <= gnngls::embed_fc_max_in_dim()) {
+        hipError_t e = gnngls::launch_embed_fc_prepare(weights, weights + 128L * in_dim, layers, in_dim,
+                                                       base + (size_t)n_layers * gnngls::ffn_packed_bytes(), (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "regret_prepare");
     }
     return GNNGLS_OK;
@@ -452,8 +458,11 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
     for (long b0 = 0; b0 < B; b0 += Bc) {
         const int bc = (int)((B - b0) < Bc ? (B - b0) : Bc);
         const long M = (long)bc * N;
+        // models.py:66; with a prepared image also ft = fc(h) of layer 0 (models.py:23), both straight from the input features
+        const bool fused_fc0 = prep && n_layers > 0 && in_dim <= gnngls::embed_fc_max_in_dim();
         { ProfScope ps(GNNGLS_PROF_EMBED, st);
-        GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st)); }   // models.py:66
+          if (fused_fc0) GNNGLS_TRY(gnngls::launch_embed_fc(feat + b0 * N * in_dim, emb_w, emb_b, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), h, ft, M, in_dim, st));
+          else GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st)); }
         for (int l = 0; l < n_layers; ++l) {                                                          // models.py:67-68
             const float *w = layers + (long)l * kLayerFloats;
             const float *fc_w = w, *attn_l = fc_w + 128L * 128, *attn_r = attn_l + 128;
@@ -462,18 +471,22 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
             const float *bn2_s = b2 + 128, *bn2_b = bn2_s + 128;
             // ft = fc(h), models.py:23: a launch of its own for the first layer (and for every layer on the fp32 path); on the bf16x3 path
             // the feed-forward launch of layer l - 1 has already written it (fc folded into that kernel's tail)
-            if (l == 0 || !prep) {
+            if ((l == 0 && !fused_fc0) || !prep) {
               ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
             // gat_combine + FFN1 + FFN2 (+ the next layer's fc) in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
+              // (the last layer's launch also applies the decision layer, models.py:69: its output is never stored)
+              const bool last = prep && l + 1 == n_layers;
               GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M,
-                                                  prep ? prep + (size_t)l * gnngls::ffn_packed_bytes() : nullptr, prep && l + 1 < n_layers, ft, st)); }
+                                                  prep ? prep + (size_t)l * gnngls::ffn_packed_bytes() : nullptr, prep && l + 1 < n_layers, ft, st,
+                                                  last ? dec_w : nullptr, last ? dec_b : nullptr, last ? y_out + b0 * N : nullptr)); }
             { float *x = h; h = h2; h2 = x; }
         }
-        { ProfScope ps(GNNGLS_PROF_DECISION, st);
+        if (!(prep && n_layers > 0)) {
+          ProfScope ps(GNNGLS_PROF_DECISION, st);
           GNNGLS_TRY(gnngls::launch_decision(h, dec_w, dec_b, y_out + b0 * N, M, st)); }               // models.py:69
     }
 #undef GNNGLS_TRY

@@ -11,6 +11,12 @@ size_t gat_rows_lds_bytes(int n);
 hipError_t launch_pack_features(const double *D, int B, int n, double scale, double minv, float *feat, hipStream_t st);
 hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, double minv, double *out, hipStream_t st);
 hipError_t launch_embed(const float *x, const float *W, const float *b, float *h, long M, int in_dim, hipStream_t st);
+// embed + the first layer's fc as one rank-in_dim pass (in_dim <= embed_fc_max_in_dim()); `image`: embed_fc_bytes() of device memory
+size_t embed_fc_bytes();
+int embed_fc_max_in_dim();
+hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, int in_dim, void *image, hipStream_t st);
+hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const void *image, float *h, float *ft, long M, int in_dim,
+                           hipStream_t st);
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
                        const float *skip, const float *bn_scale, const float *bn_shift, hipStream_t st);
 // C[M,N] = A[M,K] * W[K,N] (W row-major [K,N]); epi STORE / MASK (C = acc * (aux > 0)) / ADD (C = acc + aux)
@@ -27,7 +33,9 @@ hipError_t launch_gat_rows(const float *ft, const float *attn_l, const float *at
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
-                            float *ft_out, hipStream_t st);
+                            float *ft_out, hipStream_t st,
+                            // (bf16x3 form only) the decision layer folded into the epilogue: y_out[m] = hout[m,:] . dec_w + dec_b[0], hout not stored
+                            const float *dec_w = nullptr, const float *dec_b = nullptr, float *y_out = nullptr);
 size_t ffn_packed_bytes();      // bytes of one layer's image for the bf16x3 form of launch_ffn_fused (split weights in fragment order)
 hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_next, void *packed, hipStream_t st);
 hipError_t launch_decision(const float *h, const float *w, const float *b, float *y, long M, hipStream_t st);

@@ -59,6 +59,7 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
 __device__ __forceinline__ float max_f32(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 constexpr int kD = 128;        // embed_dim
+constexpr int kEmbedFcMaxIn = 32;     // input features the fused embed + first fc is prepared for (embed_fc_kernel)
 constexpr int kH = 8;          // heads
 constexpr int kF = 16;         // head dim
 constexpr float kSlope = 0.2f; // GATConv negative_slope default
@@ -138,6 +139,66 @@ __global__ void embed_kernel(const float *x, const float *W, const float *bias, 
             acc[u] = a + bias[c + u];
         }
         *reinterpret_cast<f32x4 *>(h + m * kD + c) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embed + the first layer's fc in one pass (models.py:66 then models.py:23 of layer 0): both are linear maps of the in_dim input
+// features, so ft = fc(embed(x)) = x A + b' with A = We^T Wfc^T [in_dim, 128], b' = Wfc be -- a rank-in_dim update per node instead
+// of a [M,128] x [128,128] GEMM behind a 2.6 GB round trip of h through HBM (1,024 x TSP100: embed 0.52 + gemm 2.18 ms -> one
+// kernel bound by its two stores).  A and b' are made once per weight image (embed_fc_prepare_kernel, fp64 sums rounded once:
+// closer to the exact product than the reference's two fp32 stages); h keeps embed_kernel's arithmetic.
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_fc_prepare_kernel(const float *__restrict__ We, const float *__restrict__ be, const float *__restrict__ Wfc,
+                                        int in_dim, float *__restrict__ A, float *__restrict__ bp) {
+    const int c = threadIdx.x;                                  // 128 threads: output column c of the fc
+    for (int d = 0; d < in_dim; ++d) {
+        double a = 0.0;
+        for (int k = 0; k < kD; ++k) a += (double)Wfc[c * kD + k] * (double)We[k * in_dim + d];
+        A[d * kD + c] = (float)a;
+    }
+    double b = 0.0;
+    for (int k = 0; k < kD; ++k) b += (double)Wfc[c * kD + k] * (double)be[k];
+    bp[c] = (float)b;
+}
+
+__global__ void embed_fc_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
+                                const float *__restrict__ A, const float *__restrict__ bp, float *__restrict__ h,
+                                float *__restrict__ ft, long M, int in_dim) {
+    const long total = M * (kD / 4);
+    const long stride = (long)gridDim.x * blockDim.x;          // a multiple of 32: the 4 columns of a thread never change
+    const long q0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)(q0 % (kD / 4)) * 4;
+    const f32x4 bb = *reinterpret_cast<const f32x4 *>(bias + c), b2 = *reinterpret_cast<const f32x4 *>(bp + c);
+    if (in_dim == 1) {                                          // the reference's feature set (datasets.py:14-20)
+        const f32x4 w = f32x4{W[c], W[c + 1], W[c + 2], W[c + 3]};
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(A + c);
+        for (long q = q0; q < total; q += stride) {
+            const float xv = x[q / (kD / 4)];
+            f32x4 hv, fv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { hv[u] = fmaf(xv, w[u], 0.f) + bb[u]; fv[u] = fmaf(xv, a[u], b2[u]); }
+            *reinterpret_cast<f32x4 *>(h + q * 4) = hv;
+            *reinterpret_cast<f32x4 *>(ft + q * 4) = fv;
+        }
+        return;
+    }
+    for (long q = q0; q < total; q += stride) {
+        const long m = q / (kD / 4);
+        f32x4 hv, fv = b2;
+        for (int u = 0; u < 4; ++u) {
+            float s = 0.f;
+            for (int d = 0; d < in_dim; ++d) s = fmaf(x[m * in_dim + d], W[(c + u) * in_dim + d], s);
+            hv[u] = s + bias[c + u];
+        }
+        for (int d = 0; d < in_dim; ++d) {
+            const float xv = x[m * in_dim + d];
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(A + d * kD + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fv[u] = fmaf(xv, a[u], fv[u]);
+        }
+        *reinterpret_cast<f32x4 *>(h + m * kD + c) = hv;
+        *reinterpret_cast<f32x4 *>(ft + m * kD + c) = fv;
     }
 }
 
@@ -863,7 +924,9 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                                                                   const float *__restrict__ b2,
                                                                   const float *__restrict__ bn2_s, const float *__restrict__ bn2_b,
                                                                   float *__restrict__ hout, long M,
-                                                                  const unsigned char *__restrict__ packed_fc, float *__restrict__ ft_out) {
+                                                                  const unsigned char *__restrict__ packed_fc, float *__restrict__ ft_out,
+                                                                  const float *__restrict__ dec_w, const float *__restrict__ dec_b,
+                                                                  float *__restrict__ y_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
     unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // ring of three weight stages
@@ -1049,6 +1112,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
     // 16-byte store, the eight tiles of a row complete its 512 bytes in L2 ----
     const long mrow = row0 + wrow + lr;
     const bool rlive = mrow < M && (!(FFN_DBG & 2) || mrow == 0);
+    float ydot = 0.f;
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) {
         const int out = ot * 16 + 4 * lq;
@@ -1062,8 +1126,18 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             v = x[r] + v;                             // x + y            (models.py:15)
             x[r] = v * sc[r] + sh[r];                 // BatchNorm1d eval (models.py:35)
         }
-        if (rlive) *reinterpret_cast<f32x4 *>(hout + mrow * kD + out) = x;
+        // the LAST layer's output goes straight into the decision layer (models.py:63,69: y = h . w + b): no store of h
+        if (dec_w) {
+            const f32x4 dw = *reinterpret_cast<const f32x4 *>(dec_w + out);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ydot = fmaf(x[r], dw[r], ydot);
+        } else if (rlive) *reinterpret_cast<f32x4 *>(hout + mrow * kD + out) = x;
         accH[ot] = x;                                 // (the layer's output in the accumulator layout: the B operand of the fc stages)
+    }
+    if (dec_w) {                                      // the row's four column quarters sit on lanes lr, lr + 16, lr + 32, lr + 48
+        ydot += __shfl_xor(ydot, 16);
+        ydot += __shfl_xor(ydot, 32);
+        if (rlive && lq == 0) y_out[mrow] = ydot + dec_b[0];
     }
     if (packed_fc) {
         // ---- the next layer's ft = fc(h) chained from the registers exactly as GEMM2 is chained from GEMM1: lane (row, q) holds outputs
@@ -1152,6 +1226,23 @@ hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, doub
     long total = (long)B * n * n;
     (void)hipGetLastError();
     hipLaunchKernelGGL(unpack_regret_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, y, B, n, scale, minv, out);
+    return hipGetLastError();
+}
+
+size_t embed_fc_bytes() { return (size_t)(kEmbedFcMaxIn + 1) * kD * sizeof(float); }
+int embed_fc_max_in_dim() { return kEmbedFcMaxIn; }
+// A [in_dim,128] then b' [128] at `image` (embed_fc_bytes() of device memory), from the embedding and the first layer's fc weights
+hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, int in_dim, void *image, hipStream_t st) {
+    float *A = (float *)image;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(embed_fc_prepare_kernel, dim3(1), dim3(kD), 0, st, We, be, Wfc, in_dim, A, A + (size_t)in_dim * kD);
+    return hipGetLastError();
+}
+hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const void *image, float *h, float *ft, long M, int in_dim,
+                           hipStream_t st) {
+    const float *A = (const float *)image;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(embed_fc_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, x, W, b, A, A + (size_t)in_dim * kD, h, ft, M, in_dim);
     return hipGetLastError();
 }
 
@@ -1254,7 +1345,7 @@ hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_nex
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
-                            float *ft_out, hipStream_t st) {
+                            float *ft_out, hipStream_t st, const float *dec_w, const float *dec_b, float *y_out) {
     if (packed) {
         const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel),
@@ -1263,7 +1354,8 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
         (void)hipGetLastError();
         const unsigned char *pk = (const unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
         hipLaunchKernelGGL(ffn_fused_bf16x3_kernel, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
-                           bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out);
+                           bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
+                           dec_w, dec_b, y_out);
         return hipGetLastError();
     }
     return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,

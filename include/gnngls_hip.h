@@ -180,6 +180,9 @@ int gnngls_regret_forward(const float *feat, const float *weights, int B, int n,
  * only.  gnngls_regret_prepare writes it for all layers into `prepared` (caller-owned device memory of
  * gnngls_regret_prepared_bytes(n_layers) bytes, valid until the weights change); gnngls_regret_forward_prepared is
  * gnngls_regret_forward reading it (prepared == NULL: the feed-forward block stays on the fp32 matrix pipe).
+ * The image also holds A = We^T Wfc0^T [in_dim,128] and b' = Wfc0 be: the embedding (models.py:57,66) and the first layer's fc
+ * (models.py:23) are both linear in the in_dim input features, so with an image (in_dim <= 32) ft = x A + b' is written by the
+ * embedding pass itself instead of a [B N,128] x [128,128] product.
  * gnngls_regret_forward itself prepares into stream-ordered scratch on every call (2 launches per layer more). */
 int64_t gnngls_regret_prepared_bytes(int n_layers);
 int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *prepared, int64_t prepared_bytes, void *stream);

@@ -204,7 +204,7 @@ def test_forward_error_fixtures(n):
                 assert (err <= regret_bound(ref)).all() or err.max() <= 3.0 * own, (n, c, k, err.max(), own)
 
 
-@pytest.mark.parametrize("in_dim,n,B", [(3, 12, 2), (2, 33, 1)])
+@pytest.mark.parametrize("in_dim,n,B", [(3, 12, 2), (2, 33, 1), (40, 8, 1)])   # (40 > 32: embed and the first fc as two launches)
 def test_forward_multi_feature_input(in_dim, n, B):
     """Input width other than 1 (test.py:41 takes it from the dataset; the reference's feature sets are built by
     datasets.py:14-34): embed layer [128, in_dim], same 1e-5 bar against the fp64 oracle."""
