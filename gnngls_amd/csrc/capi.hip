@@ -413,8 +413,8 @@ int gnngls_regret_prepare(const float *weights, int in_dim, int n_layers, void *
         if (e != hipSuccess) return hip_fail(e, "regret_prepare");
     }
     if (n_layers > 0 && in_dim <= gnngls::embed_fc_max_in_dim()) {
-        hipError_t e = gnngls::launch_embed_fc_prepare(weights, weights + 128L * in_dim, layers, in_dim,
-                                                       base + (size_t)n_layers * gnngls::ffn_packed_bytes(), (hipStream_t)stream);
+        hipError_t e = gnngls::launch_embed_fc_prepare(weights, weights + 128L * in_dim, layers, layers + 128L * 128, layers + 128L * 128 + 128,
+                                                       in_dim, base + (size_t)n_layers * gnngls::ffn_packed_bytes(), (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "regret_prepare");
     }
     return GNNGLS_OK;
@@ -460,8 +460,12 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
         const long M = (long)bc * N;
         // models.py:66; with a prepared image also ft = fc(h) of layer 0 (models.py:23), both straight from the input features
         const bool fused_fc0 = prep && n_layers > 0 && in_dim <= gnngls::embed_fc_max_in_dim();
+        static const bool no_rank1 = getenv("GNNGLS_GAT_RANK1") && atoi(getenv("GNNGLS_GAT_RANK1")) == 0;      // (A/B runs)
+        const bool rank1_gat0 = fused_fc0 && in_dim == 1 && n <= 255 && !no_rank1;
         { ProfScope ps(GNNGLS_PROF_EMBED, st);
-          if (fused_fc0) GNNGLS_TRY(gnngls::launch_embed_fc(feat + b0 * N * in_dim, emb_w, emb_b, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), h, ft, M, in_dim, st));
+          // (one input feature: the first GATConv runs in its rank-1 form below and no ft is written)
+          if (fused_fc0) GNNGLS_TRY(gnngls::launch_embed_fc(feat + b0 * N * in_dim, emb_w, emb_b, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), h,
+                                                            rank1_gat0 ? nullptr : ft, M, in_dim, st));
           else GNNGLS_TRY(gnngls::launch_embed(feat + b0 * N * in_dim, emb_w, emb_b, h, M, in_dim, st)); }
         for (int l = 0; l < n_layers; ++l) {                                                          // models.py:67-68
             const float *w = layers + (long)l * kLayerFloats;
@@ -475,7 +479,9 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
               ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
-              GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
+              if (l == 0 && rank1_gat0)
+                  GNNGLS_TRY(gnngls::launch_gat_rows_rank1(feat + b0 * N, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), bc, n, part, part_ms, st));
+              else GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
             // gat_combine + FFN1 + FFN2 (+ the next layer's fc) in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
               // (the last layer's launch also applies the decision layer, models.py:69: its output is never stored)

@@ -14,7 +14,10 @@ hipError_t launch_embed(const float *x, const float *W, const float *b, float *h
 // embed + the first layer's fc as one rank-in_dim pass (in_dim <= embed_fc_max_in_dim()); `image`: embed_fc_bytes() of device memory
 size_t embed_fc_bytes();
 int embed_fc_max_in_dim();
-hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, int in_dim, void *image, hipStream_t st);
+hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, const float *attn_l, const float *attn_r,
+                                   int in_dim, void *image, hipStream_t st);
+// in_dim == 1: the first GATConv from the one input feature and the same image (partials as launch_gat_rows on ft = x A + b')
+hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st);
 hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const void *image, float *h, float *ft, long M, int in_dim,
                            hipStream_t st);
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,

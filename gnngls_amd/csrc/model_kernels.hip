@@ -150,6 +150,7 @@ __global__ void embed_kernel(const float *x, const float *W, const float *bias, 
 // closer to the exact product than the reference's two fp32 stages); h keeps embed_kernel's arithmetic.
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_fc_prepare_kernel(const float *__restrict__ We, const float *__restrict__ be, const float *__restrict__ Wfc,
+                                        const float *__restrict__ attn_l, const float *__restrict__ attn_r,
                                         int in_dim, float *__restrict__ A, float *__restrict__ bp) {
     const int c = threadIdx.x;                                  // 128 threads: output column c of the fc
     for (int d = 0; d < in_dim; ++d) {
@@ -160,6 +161,20 @@ __global__ void embed_fc_prepare_kernel(const float *__restrict__ We, const floa
     double b = 0.0;
     for (int k = 0; k < kD; ++k) b += (double)Wfc[c * kD + k] * (double)be[k];
     bp[c] = (float)b;
+    // in_dim == 1: the first layer's attention logits are affine in the node's one feature, el = x al[h] + bl[h], er likewise
+    // (GATConv: (ft * attn).sum(-1) with ft = x A + b'): al | bl | ar | br, 8 heads each, behind b' (gat_rows_rank1_kernel)
+    if (in_dim == 1 && c < 4 * kH) {
+        const int what = c / kH, h = c % kH;
+        const float *att = (what < 2) ? attn_l : attn_r;
+        double v = 0.0;
+        for (int j = 0; j < kF; ++j) {
+            const int col = h * kF + j;
+            double t = 0.0;
+            for (int k = 0; k < kD; ++k) t += (double)Wfc[col * kD + k] * ((what & 1) ? (double)be[k] : (double)We[k]);
+            v += t * (double)att[col];
+        }
+        bp[kD + c] = (float)v;
+    }
 }
 
 __global__ void embed_fc_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
@@ -179,7 +194,7 @@ __global__ void embed_fc_kernel(const float *__restrict__ x, const float *__rest
 #pragma unroll
             for (int u = 0; u < 4; ++u) { hv[u] = fmaf(xv, w[u], 0.f) + bb[u]; fv[u] = fmaf(xv, a[u], b2[u]); }
             *reinterpret_cast<f32x4 *>(h + q * 4) = hv;
-            *reinterpret_cast<f32x4 *>(ft + q * 4) = fv;
+            if (ft) *reinterpret_cast<f32x4 *>(ft + q * 4) = fv;      // (nullptr: the first GATConv runs in its rank-1 form and needs no ft)
         }
         return;
     }
@@ -590,6 +605,143 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
             float *mo = mb + (i < j ? 0 : side_stride * (2 * kH)) + (size_t)nodeS[js] * (2 * kH);
 #pragma unroll
             for (int u = 0; u < HU; ++u) { mo[hb + h0 + u] = mm[u]; mo[kH + hb + h0 + u] = ws[u]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1': the FIRST GATConv when the model has ONE input feature (the reference's default feature set, datasets.py:14-20).  Embedding and
+// fc are linear, so ft[s] = x_s A + b' (embed_fc_kernel), the logits are affine in x_s (el = x al[h] + bl[h], er likewise) and the
+// aggregation sum_s w[d,s,h] ft[s, 16 h + j] = (sum_s w x_s) A[16 h + j] + (sum_s w) b'[16 h + j]: TWO weighted sums per
+// (destination, head) instead of sixteen -- the weights, shifts and exclusions are gat_rows_kernel's, term for term, but nothing is
+// left for the matrix pipe to do and no ft tile is staged.  One workgroup per (instance, TSP row i); a wavefront owns 64 destinations
+// x 4 heads, lane = destination, and walks the n - 1 sources with uniform LDS reads.  Writes gat_rows_kernel's partials.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gat_rows_rank1_kernel(const float *__restrict__ x, const float *__restrict__ img, int n,
+                                                             float *__restrict__ part, float *__restrict__ part_ms) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int N = n * (n - 1) / 2, ns = n - 1;
+    const int b = blockIdx.x / n, i = blockIdx.x % n;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *eaS = reinterpret_cast<float *>(smem);            // [ns][8] exp(el - max1)
+    float *ebS = eaS + (size_t)ns * kH;                      // [ns][8] exp(0.2 (el - max1))
+    float *xS = ebS + (size_t)ns * kH;                       // [ns] the sources' feature
+    int *nodeS = reinterpret_cast<int *>(xS + ns);           // [ns] global node id of slot
+    float *top = reinterpret_cast<float *>(nodeS + ns);      // [8][4]: max1, max2, argmax1 (int bits), direct-path flag
+    const float *A = img, *bp = img + kD, *al = bp + kD, *bl = al + kH, *ar = bl + kH, *br = ar + kH;
+    const float kLog2e = 1.4426950408889634f;
+    for (int s = tid; s < ns; s += nthreads) {
+        const int k = s < i ? s : s + 1;
+        const int node = k < i ? pair_index(k, i, n) : pair_index(i, k, n);
+        nodeS[s] = node;
+        xS[s] = x[(size_t)b * N + node];
+    }
+    __syncthreads();
+    if (tid < 32 * kH) {   // top-2 of el per head over the row's sources, as in gat_rows_kernel
+        const int h = tid >> 5, l32 = tid & 31;
+        const float a = al[h], c = bl[h];
+        float m1 = -INFINITY, m2 = -INFINITY; int a1 = -1;
+        for (int s = l32; s < ns; s += 32) {
+            const float v = fmaf(xS[s], a, c);
+            if (v > m1) { m2 = m1; m1 = v; a1 = s; } else if (v > m2) { m2 = v; }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            const float om1 = __shfl_xor(m1, o, 32), om2 = __shfl_xor(m2, o, 32);
+            const int oa1 = __shfl_xor(a1, o, 32);
+            const bool take = om1 > m1 || (om1 == m1 && oa1 >= 0 && (a1 < 0 || oa1 < a1));
+            const float lo1 = take ? m1 : om1;
+            const float hi2 = take ? om2 : m2;
+            if (take) { m1 = om1; a1 = oa1; }
+            m2 = lo1 > hi2 ? lo1 : hi2;
+        }
+        if (l32 == 0) { top[h * 4 + 0] = m1; top[h * 4 + 1] = m2; top[h * 4 + 2] = __int_as_float(a1);
+                        top[h * 4 + 3] = (m1 - m2 > 60.f) ? 1.f : 0.f; }
+    }
+    __syncthreads();
+    for (int q = tid; q < ns * kH; q += nthreads) {
+        const int h = q % kH;
+        const float d = (fmaf(xS[q / kH], al[h], bl[h]) - top[h * 4]) * kLog2e;
+        eaS[q] = __builtin_amdgcn_exp2f(d);
+        ebS[q] = __builtin_amdgcn_exp2f(kSlope * d);
+    }
+    __syncthreads();
+
+    constexpr int HU = 4;
+    if ((wave >> 1) * 64 >= ns) return;                      // (wavefronts that only helped with the tables: no barrier follows)
+    const int h0 = (wave & 1) * HU, js = (wave >> 1) * 64 + lane;     // this lane's destination slot, this wavefront's heads
+    const bool dlive = js < ns;
+    const int jsc = dlive ? js : ns - 1;
+    const float xd = xS[jsc];
+    float er[HU], mm[HU], nm[HU], cpos[HU], cneg[HU], ws[HU], wx[HU];
+    bool direct = false;
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+        const int h = h0 + u;
+        er[u] = fmaf(xd, ar[h], br[h]);
+        const float m = ((__float_as_int(top[h * 4 + 2]) == js) ? top[h * 4 + 1] : top[h * 4 + 0]) + er[u];
+        mm[u] = m > 0.f ? m : kSlope * m;
+        nm[u] = -mm[u] * kLog2e;
+        const float t = er[u] + top[h * 4 + 0];
+        cpos[u] = __builtin_amdgcn_exp2f(fminf(t - mm[u], 80.f) * kLog2e);
+        cneg[u] = __builtin_amdgcn_exp2f(fminf(kSlope * t - mm[u], 80.f) * kLog2e);
+        ws[u] = 0.f; wx[u] = 0.f;
+        direct = direct || top[h * 4 + 3] != 0.f;            // wave-uniform
+    }
+    if (!direct) {
+        auto run = [&](int s_lo, int s_hi, auto masked) {
+            constexpr bool MASK = decltype(masked)::value;
+            for (int s = s_lo; s < s_hi; ++s) {              // (uniform addresses: one LDS cycle per read)
+                const float xs = xS[s];
+                const f32x4 ea = *reinterpret_cast<const f32x4 *>(eaS + s * kH + h0);
+                const f32x4 eb = *reinterpret_cast<const f32x4 *>(ebS + s * kH + h0);
+#pragma unroll
+                for (int u = 0; u < HU; ++u) {
+                    float w = max_f32(ea[u] * cpos[u], eb[u] * cneg[u]);
+                    if (MASK) w = (s == js) ? 0.f : w;           // no self loop
+                    ws[u] += w;
+                    wx[u] = fmaf(w, xs, wx[u]);
+                }
+            }
+        };
+        // only the sources in this wavefront's own destination range can be a lane's own node
+        const int d_lo = (wave >> 1) * 64, d_hi = d_lo + 64 < ns ? d_lo + 64 : ns;
+        run(0, d_lo, std::false_type{});
+        run(d_lo, d_hi, std::true_type{});
+        run(d_hi, ns, std::false_type{});
+    } else {
+        for (int s = 0; s < ns; ++s) {
+            const float xs = xS[s];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                float v = fmaf(xs, al[h0 + u], bl[h0 + u]) + er[u];
+                v = fmaxf(v, kSlope * v);                    // LeakyReLU(x) = max(x, 0.2x)
+                float w = __builtin_amdgcn_exp2f(fmaf(v, kLog2e, nm[u]));
+                w = (s == js) ? 0.f : w;
+                ws[u] += w;
+                wx[u] = fmaf(w, xs, wx[u]);
+            }
+        }
+    }
+    if (dlive) {
+        const int j = js < i ? js : js + 1;
+        const size_t node = (size_t)nodeS[js];
+        const size_t side_stride = (size_t)gridDim.x / n * N;        // B*N nodes per side
+        float *po = part + ((size_t)b * N + (i < j ? 0 : side_stride) + node) * kD;
+        float *mo = part_ms + ((size_t)b * N + (i < j ? 0 : side_stride) + node) * (2 * kH);
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            const int h = h0 + u;
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(A + h * kF + 4 * v4), c = *reinterpret_cast<const f32x4 *>(bp + h * kF + 4 * v4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(wx[u], a[e], ws[u] * c[e]);
+                *reinterpret_cast<f32x4 *>(po + h * kF + 4 * v4) = o;
+            }
+            mo[h] = mm[u]; mo[kH + h] = ws[u];
         }
     }
 }
@@ -1229,20 +1381,32 @@ hipError_t launch_unpack_regret(const float *y, int B, int n, double scale, doub
     return hipGetLastError();
 }
 
-size_t embed_fc_bytes() { return (size_t)(kEmbedFcMaxIn + 1) * kD * sizeof(float); }
+size_t embed_fc_bytes() { return ((size_t)(kEmbedFcMaxIn + 1) * kD + 4 * kH) * sizeof(float); }
 int embed_fc_max_in_dim() { return kEmbedFcMaxIn; }
-// A [in_dim,128] then b' [128] at `image` (embed_fc_bytes() of device memory), from the embedding and the first layer's fc weights
-hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, int in_dim, void *image, hipStream_t st) {
+// A [in_dim,128], b' [128] (and for in_dim == 1 the logit coefficients al | bl | ar | br [8] each) at `image` (embed_fc_bytes() of
+// device memory), from the embedding and the first layer's fc and attention weights
+hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, const float *attn_l, const float *attn_r,
+                                   int in_dim, void *image, hipStream_t st) {
     float *A = (float *)image;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(embed_fc_prepare_kernel, dim3(1), dim3(kD), 0, st, We, be, Wfc, in_dim, A, A + (size_t)in_dim * kD);
+    hipLaunchKernelGGL(embed_fc_prepare_kernel, dim3(1), dim3(kD), 0, st, We, be, Wfc, attn_l, attn_r, in_dim, A, A + (size_t)in_dim * kD);
     return hipGetLastError();
 }
+// ft == nullptr: only h is written (in_dim == 1 with the rank-1 first GATConv)
 hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const void *image, float *h, float *ft, long M, int in_dim,
                            hipStream_t st) {
     const float *A = (const float *)image;
     (void)hipGetLastError();
     hipLaunchKernelGGL(embed_fc_kernel, dim3(grid_for(M * 32, 256)), dim3(256), 0, st, x, W, b, A, A + (size_t)in_dim * kD, h, ft, M, in_dim);
+    return hipGetLastError();
+}
+// the first GATConv from the one input feature (in_dim == 1): same partials as launch_gat_rows on ft = x A + b'
+hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st) {
+    const float *A = (const float *)image;
+    const int units = ((n - 1 + 63) / 64) * 2;                 // (64 destinations, 4 heads) per wavefront
+    const size_t lds = (size_t)(n - 1) * (2 + 2 * kH) * sizeof(float) + kH * 4 * sizeof(float) + 16;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(gat_rows_rank1_kernel, dim3((unsigned)(B * n)), dim3(64 * (units < 4 ? 4 : units)), lds, st, x, A, n, part, part_ms);
     return hipGetLastError();
 }
 
