@@ -385,6 +385,9 @@ def kernel_rooflines(prof, n, B_chunk, n_layers):
         add("gat_aggregate", ["gat_rows"], "mfma", k1_flops, PEAK_MFMA_F32_TFLOPS, "TFLOP/s")
     else:
         add("gat_aggregate", ["gat_rows"], "hbm", k1_bytes, PEAK_HBM_GBS, "GB/s")
+    # K1' (round 6): the first GATConv in its rank-1 form (one input feature): no MFMA, no ft tile; its algorithmic traffic is what it
+    # writes -- two partials of 512 + 64 B per line-graph node -- over the node's one feature
+    add("gat_rank1", ["gat_rows_rank1"], "hbm", (2 * (512.0 + 64.0) + 4.0) * M, PEAK_HBM_GBS, "GB/s")
     traffic = load_traffic()
     for name, v in out.items():
         if name in traffic and "hbm_bytes_per_row" in traffic[name]:

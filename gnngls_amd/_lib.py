@@ -53,7 +53,7 @@ SIGNATURES = {
     "gnngls_profile_set_executed_evals": [_vp],
 }
 
-PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_combine(unused)", "gemm_ffn1(unused)", "gemm_ffn2(unused)",
+PROF_KINDS = ["pack_features", "embed", "gemm_fc", "gat_rows", "gat_rows_rank1", "gemm_ffn1(unused)", "gemm_ffn2(unused)",
               "decision", "unpack_regret", "nearest_neighbor", "tour_cost", "gls", "ffn_fused",
               "train_colsum", "train_elementwise", "train_gemm_bwd", "train_gemm_tn", "train_gat_bwd"]
 

@@ -478,10 +478,12 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
             if ((l == 0 && !fused_fc0) || !prep) {
               ProfScope ps(GNNGLS_PROF_GEMM_FC, st);
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
-            { ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
-              if (l == 0 && rank1_gat0)
-                  GNNGLS_TRY(gnngls::launch_gat_rows_rank1(feat + b0 * N, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), bc, n, part, part_ms, st));
-              else GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
+            if (l == 0 && rank1_gat0) {
+              ProfScope ps(GNNGLS_PROF_GAT_ROWS_RANK1, st);
+              GNNGLS_TRY(gnngls::launch_gat_rows_rank1(feat + b0 * N, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), bc, n, part, part_ms, st));
+            } else {
+              ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
+              GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
             // gat_combine + FFN1 + FFN2 (+ the next layer's fc) in one launch; the hidden layer and x = BN1(h + GAT) never touch HBM
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
               // (the last layer's launch also applies the decision layer, models.py:69: its output is never stored)

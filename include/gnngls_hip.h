@@ -265,7 +265,7 @@ int gnngls_debug_set_stamp_buffer(void *device_buffer);
  * synchronises the recorded events, sums milliseconds and launch counts per class (arrays of
  * GNNGLS_PROF_KINDS entries) and clears the log. */
 enum {
-    GNNGLS_PROF_PACK = 0, GNNGLS_PROF_EMBED, GNNGLS_PROF_GEMM_FC, GNNGLS_PROF_GAT_ROWS, GNNGLS_PROF_GAT_COMBINE,
+    GNNGLS_PROF_PACK = 0, GNNGLS_PROF_EMBED, GNNGLS_PROF_GEMM_FC, GNNGLS_PROF_GAT_ROWS, GNNGLS_PROF_GAT_ROWS_RANK1 /* (the slot of the retired gat_combine) */,
     GNNGLS_PROF_GEMM_FFN1, GNNGLS_PROF_GEMM_FFN2, GNNGLS_PROF_DECISION, GNNGLS_PROF_UNPACK,
     GNNGLS_PROF_NEAREST_NEIGHBOR, GNNGLS_PROF_TOUR_COST, GNNGLS_PROF_GLS, GNNGLS_PROF_FFN_FUSED,
     GNNGLS_PROF_TRAIN_COLSUM, GNNGLS_PROF_TRAIN_ELEMENTWISE, GNNGLS_PROF_TRAIN_GEMM_BWD, GNNGLS_PROF_TRAIN_GEMM_TN,
