@@ -284,6 +284,10 @@ struct LaneTour {      // positions lane, lane + 64, ... (SL slots) of the tour 
 template <int SL, class TT>
 __device__ __forceinline__ LaneTour<SL> load_lane_tour(const TT *t, int n, int lane) {
     LaneTour<SL> L;
+    // (four-slot builds: the clamped positions are loop-invariant, and as such the compiler kept them alive across the whole kernel -- in
+    // scratch, reloaded with a wait in front of every one of these reads; recomputed from an opaque copy of the lane they cost two
+    // vector instructions each)
+    if constexpr (SL >= 4) asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int q = 0; q < SL; ++q) {
         const int p = lane + q * kWave <= n ? lane + q * kWave : n;
