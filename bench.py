@@ -386,8 +386,10 @@ def kernel_rooflines(prof, n, B_chunk, n_layers):
     else:
         add("gat_aggregate", ["gat_rows"], "hbm", k1_bytes, PEAK_HBM_GBS, "GB/s")
     # K1' (round 6): the first GATConv in its rank-1 form (one input feature): no MFMA, no ft tile; its algorithmic traffic is what it
-    # writes -- two partials of 512 + 64 B per line-graph node -- over the node's one feature
-    add("gat_rank1", ["gat_rows_rank1"], "hbm", (2 * (512.0 + 64.0) + 4.0) * M, PEAK_HBM_GBS, "GB/s")
+    # writes -- two compact partials of 24 floats (shift, sum of weights, sum of weights x feature per head) per line-graph node --
+    # over the node's one feature.  It is bound by its vector instructions (one softmax weight per (destination, source, head)), so
+    # the HBM fraction is small by construction.
+    add("gat_rank1", ["gat_rows_rank1"], "hbm", (2 * 96.0 + 4.0) * M, PEAK_HBM_GBS, "GB/s")
     traffic = load_traffic()
     for name, v in out.items():
         if name in traffic and "hbm_bytes_per_row" in traffic[name]:

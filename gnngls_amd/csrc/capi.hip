@@ -462,7 +462,12 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
         const bool fused_fc0 = prep && n_layers > 0 && in_dim <= gnngls::embed_fc_max_in_dim();
         static const bool no_rank1 = getenv("GNNGLS_GAT_RANK1") && atoi(getenv("GNNGLS_GAT_RANK1")) == 0;      // (A/B runs)
         const bool rank1_gat0 = fused_fc0 && in_dim == 1 && n <= 255 && !no_rank1;
-        { ProfScope ps(GNNGLS_PROF_EMBED, st);
+        // ... and then the first feed-forward launch forms its input from the one feature and the compact partials (LR0): no embedding
+        // pass at all, neither h_0 nor ft_0 nor 128-wide partials of the first layer in memory (GNNGLS_GAT_RANK1=2: keep them, A/B runs)
+        static const bool keep_h0 = getenv("GNNGLS_GAT_RANK1") && atoi(getenv("GNNGLS_GAT_RANK1")) == 2;
+        const bool lr0 = rank1_gat0 && !keep_h0;
+        const float *img0 = (const float *)(prep ? prep + (size_t)n_layers * gnngls::ffn_packed_bytes() : nullptr);
+        if (!lr0) { ProfScope ps(GNNGLS_PROF_EMBED, st);
           // (one input feature: the first GATConv runs in its rank-1 form below and no ft is written)
           if (fused_fc0) GNNGLS_TRY(gnngls::launch_embed_fc(feat + b0 * N * in_dim, emb_w, emb_b, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), h,
                                                             rank1_gat0 ? nullptr : ft, M, in_dim, st));
@@ -480,7 +485,7 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
               GNNGLS_TRY(gnngls::launch_gemm(gnngls::GEMM_EPI_STORE, h, fc_w, ft, M, 128, 128, nullptr, nullptr, nullptr, nullptr, st)); }
             if (l == 0 && rank1_gat0) {
               ProfScope ps(GNNGLS_PROF_GAT_ROWS_RANK1, st);
-              GNNGLS_TRY(gnngls::launch_gat_rows_rank1(feat + b0 * N, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), bc, n, part, part_ms, st));
+              GNNGLS_TRY(gnngls::launch_gat_rows_rank1(feat + b0 * N, prep + (size_t)n_layers * gnngls::ffn_packed_bytes(), bc, n, part, part_ms, st, lr0));
             } else {
               ProfScope ps(GNNGLS_PROF_GAT_ROWS, st);
               GNNGLS_TRY(gnngls::launch_gat_rows(ft, attn_l, attn_r, bc, n, part, part_ms, st)); }
@@ -488,9 +493,11 @@ int gnngls_regret_forward_prepared(const float *feat, const float *weights, cons
             { ProfScope ps(GNNGLS_PROF_FFN_FUSED, st);
               // (the last layer's launch also applies the decision layer, models.py:69: its output is never stored)
               const bool last = prep && l + 1 == n_layers;
-              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M,
+              const bool lr = l == 0 && lr0;
+              GNNGLS_TRY(gnngls::launch_ffn_fused(part, part_ms, lr ? feat + b0 * N : h, bn1_s, bn1_b, w1, b1, w2, b2, bn2_s, bn2_b, h2, M,
                                                   prep ? prep + (size_t)l * gnngls::ffn_packed_bytes() : nullptr, prep && l + 1 < n_layers, ft, st,
-                                                  last ? dec_w : nullptr, last ? dec_b : nullptr, last ? y_out + b0 * N : nullptr)); }
+                                                  last ? dec_w : nullptr, last ? dec_b : nullptr, last ? y_out + b0 * N : nullptr,
+                                                  lr ? img0 : nullptr, lr ? emb_w : nullptr, lr ? emb_b : nullptr)); }
             { float *x = h; h = h2; h2 = x; }
         }
         if (!(prep && n_layers > 0)) {

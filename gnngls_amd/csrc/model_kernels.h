@@ -17,7 +17,9 @@ int embed_fc_max_in_dim();
 hipError_t launch_embed_fc_prepare(const float *We, const float *be, const float *Wfc, const float *attn_l, const float *attn_r,
                                    int in_dim, void *image, hipStream_t st);
 // in_dim == 1: the first GATConv from the one input feature and the same image (partials as launch_gat_rows on ft = x A + b')
-hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st);
+// compact: [2][B N][24] = (shift, sum of weights, sum of weights x feature) per head into `part` (for launch_ffn_fused's lr_img form)
+hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st,
+                                 bool compact = false);
 hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const void *image, float *h, float *ft, long M, int in_dim,
                            hipStream_t st);
 hipError_t launch_gemm(int epi, const float *A, const float *W, float *C, long M, int N, int K, const float *bias,
@@ -38,7 +40,10 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
                             const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
                             float *ft_out, hipStream_t st,
                             // (bf16x3 form only) the decision layer folded into the epilogue: y_out[m] = hout[m,:] . dec_w + dec_b[0], hout not stored
-                            const float *dec_w = nullptr, const float *dec_b = nullptr, float *y_out = nullptr);
+                            const float *dec_w = nullptr, const float *dec_b = nullptr, float *y_out = nullptr,
+                            // (bf16x3 form, first layer of a one-feature model) lr_img = the embed-fc image: `part` then holds
+                            // launch_gat_rows_rank1's compact partials and `hin` the [M] input features; emb_w / emb_b = the embedding
+                            const float *lr_img = nullptr, const float *emb_w = nullptr, const float *emb_b = nullptr);
 size_t ffn_packed_bytes();      // bytes of one layer's image for the bf16x3 form of launch_ffn_fused (split weights in fragment order)
 hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_next, void *packed, hipStream_t st);
 hipError_t launch_decision(const float *h, const float *w, const float *b, float *y, long M, hipStream_t st);

@@ -617,6 +617,7 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
 // left for the matrix pipe to do and no ft tile is staged.  One workgroup per (instance, TSP row i); a wavefront owns 64 destinations
 // x 4 heads, lane = destination, and walks the n - 1 sources with uniform LDS reads.  Writes gat_rows_kernel's partials.
 // ---------------------------------------------------------------------------------------------
+template <bool COMPACT>
 __global__ __launch_bounds__(512) void gat_rows_rank1_kernel(const float *__restrict__ x, const float *__restrict__ img, int n,
                                                              float *__restrict__ part, float *__restrict__ part_ms) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -728,6 +729,13 @@ __global__ __launch_bounds__(512) void gat_rows_rank1_kernel(const float *__rest
         const int j = js < i ? js : js + 1;
         const size_t node = (size_t)nodeS[js];
         const size_t side_stride = (size_t)gridDim.x / n * N;        // B*N nodes per side
+        if constexpr (COMPACT) {
+            // (shift, sum of weights, sum of weights x feature) per head: all the first layer's feed-forward launch needs (LR0)
+            float *qo = part + ((size_t)b * N + (i < j ? 0 : side_stride) + node) * (3 * kH);
+#pragma unroll
+            for (int u = 0; u < HU; ++u) { qo[h0 + u] = mm[u]; qo[kH + h0 + u] = ws[u]; qo[2 * kH + h0 + u] = wx[u]; }
+            return;
+        }
         float *po = part + ((size_t)b * N + (i < j ? 0 : side_stride) + node) * kD;
         float *mo = part_ms + ((size_t)b * N + (i < j ? 0 : side_stride) + node) * (2 * kH);
 #pragma unroll
@@ -1069,6 +1077,12 @@ __global__ void ffn_pack_fc_bf16x3_kernel(const float *__restrict__ Wfc, unsigne
     *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
 }
 
+// LR0 (the first layer of a model with ONE input feature, behind gat_rows_rank1_kernel<true>): `part` holds that kernel's compact
+// partials [2][M][24] = (shift, sum of weights, sum of weights x feature) per head, `hin` the [M] input features; the layer's input
+// h = x We + be (models.py:66, embed_kernel's arithmetic) and its GATConv output rho A + b' (rho = the softmax-weighted mean of the
+// neighbours' features, per head) are formed here from 13 scalars per row instead of 1.7 KB -- neither h nor ft nor the 128-wide
+// partials of the first layer exist in memory.
+template <bool LR0>
 __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
                                                                   const float *__restrict__ hin,
                                                                   const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
@@ -1078,7 +1092,9 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                                                                   float *__restrict__ hout, long M,
                                                                   const unsigned char *__restrict__ packed_fc, float *__restrict__ ft_out,
                                                                   const float *__restrict__ dec_w, const float *__restrict__ dec_b,
-                                                                  float *__restrict__ y_out) {
+                                                                  float *__restrict__ y_out,
+                                                                  const float *__restrict__ lr_img, const float *__restrict__ emb_w,
+                                                                  const float *__restrict__ emb_b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
     unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // ring of three weight stages
@@ -1093,6 +1109,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
 
     // ---- stage the x tile: x = BN1(h + merge(partials))  (gat_combine fused; models.py:15,24,28), as in ffn_fused_kernel ----
     constexpr int PB = 4;
+    if constexpr (!LR0) {
     for (int it0 = 0; it0 < (FB_M * 32) / 512; it0 += PB) {
         f32x4 p0[PB], p1[PB], hv[PB];
         float m0[PB], s0[PB], m1[PB], s1[PB];
@@ -1125,6 +1142,44 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                 o4[v] = live[u] ? o : 0.f;
             }
             *reinterpret_cast<f32x4 *>(Xs + row * LDX + c) = o4;
+        }
+    }
+    } else {
+        const int c = (tid & 31) * 4, hd = c >> 4;           // (the columns of a thread are the same in every slot)
+        const f32x4 we = f32x4{emb_w[c], emb_w[c + 1], emb_w[c + 2], emb_w[c + 3]}, be4 = *reinterpret_cast<const f32x4 *>(emb_b + c);
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(lr_img + c), bp4 = *reinterpret_cast<const f32x4 *>(lr_img + kD + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(bn1_s + c), sh = *reinterpret_cast<const f32x4 *>(bn1_b + c);
+        for (int it0 = 0; it0 < (FB_M * 32) / 512; it0 += PB) {
+            float xv[PB], m0[PB], s0[PB], w0[PB], m1[PB], s1[PB], w1[PB];
+            bool live[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int row = ((it0 + u) * 512 + tid) >> 5;
+                const long m = row0 + row;
+                live[u] = m < M;
+                const long mc = (FFN_DBG & 2) ? 0 : (live[u] ? m : 0);
+                const float *q0 = part + mc * (3 * kH), *q1 = part + (M + mc) * (3 * kH);
+                xv[u] = hin[mc];
+                m0[u] = q0[hd]; s0[u] = q0[kH + hd]; w0[u] = q0[2 * kH + hd];
+                m1[u] = q1[hd]; s1[u] = q1[kH + hd]; w1[u] = q1[2 * kH + hd];
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int row = ((it0 + u) * 512 + tid) >> 5;
+                const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
+                const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
+                const float inv = 1.f / (s0[u] * a0 + s1[u] * a1);
+                const float rho = (w0[u] * a0 + w1[u] * a1) * inv;
+                f32x4 o4;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float hv = fmaf(xv[u], we[v], 0.f) + be4[v];            // models.py:66, as embed_kernel
+                    const float g = fmaf(rho, a4[v], bp4[v]);                      // GATConv of layer 0: rho A + b'
+                    const float o = (hv + g) * sc[v] + sh[v];
+                    o4[v] = live[u] ? o : 0.f;
+                }
+                *reinterpret_cast<f32x4 *>(Xs + row * LDX + c) = o4;
+            }
         }
     }
 
@@ -1401,12 +1456,13 @@ hipError_t launch_embed_fc(const float *x, const float *W, const float *b, const
     return hipGetLastError();
 }
 // the first GATConv from the one input feature (in_dim == 1): same partials as launch_gat_rows on ft = x A + b'
-hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st) {
+hipError_t launch_gat_rows_rank1(const float *x, const void *image, int B, int n, float *part, float *part_ms, hipStream_t st, bool compact) {
     const float *A = (const float *)image;
     const int units = ((n - 1 + 63) / 64) * 2;                 // (64 destinations, 4 heads) per wavefront
     const size_t lds = (size_t)(n - 1) * (2 + 2 * kH) * sizeof(float) + kH * 4 * sizeof(float) + 16;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gat_rows_rank1_kernel, dim3((unsigned)(B * n)), dim3(64 * (units < 4 ? 4 : units)), lds, st, x, A, n, part, part_ms);
+    if (compact) hipLaunchKernelGGL(gat_rows_rank1_kernel<true>, dim3((unsigned)(B * n)), dim3(64 * (units < 4 ? 4 : units)), lds, st, x, A, n, part, part_ms);
+    else hipLaunchKernelGGL(gat_rows_rank1_kernel<false>, dim3((unsigned)(B * n)), dim3(64 * (units < 4 ? 4 : units)), lds, st, x, A, n, part, part_ms);
     return hipGetLastError();
 }
 
@@ -1509,17 +1565,25 @@ hipError_t launch_ffn_pack(const float *W1, const float *W2, const float *fc_nex
 hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float *hin, const float *bn1_s,
                             const float *bn1_b, const float *W1, const float *b1, const float *W2, const float *b2,
                             const float *bn2_s, const float *bn2_b, float *hout, long M, const void *packed, bool has_fc_next,
-                            float *ft_out, hipStream_t st, const float *dec_w, const float *dec_b, float *y_out) {
+                            float *ft_out, hipStream_t st, const float *dec_w, const float *dec_b, float *y_out,
+                            const float *lr_img, const float *emb_w, const float *emb_b) {
     if (packed) {
         const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         (void)hipGetLastError();
         const unsigned char *pk = (const unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
-        hipLaunchKernelGGL(ffn_fused_bf16x3_kernel, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
-                           bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
-                           dec_w, dec_b, y_out);
+        if (lr_img)        // (`part` = the compact partials of gat_rows_rank1_kernel<true>, `hin` = the [M] input features)
+            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<true>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
+                               bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
+                               dec_w, dec_b, y_out, lr_img, emb_w, emb_b);
+        else
+            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<false>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
+                               bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
+                               dec_w, dec_b, y_out, nullptr, nullptr, nullptr);
         return hipGetLastError();
     }
     return launch_ffn_mode<FFN_INFER>(part, part_ms, hin, bn1_s, bn1_b, W1, b1, W2, b2, bn2_s, bn2_b, hout, M, nullptr,

@@ -38,7 +38,7 @@ for k, (ms, cnt) in prof.items():
         extra = f"  {2.0 * M * 128 * 128 / (avg * 1e-3) / 1e12:.1f} TFLOP/s"
     if k == "ffn_fused":
         extra = f"  {4.0 * M * 128 * 512 / (avg * 1e-3) / 1e12:.1f} TFLOP/s"
-    if k in ("gat_rows", "gat_rows_rank1"):
+    if k == "gat_rows":
         extra = f"  {1600.0 * M / (avg * 1e-3) / 1e9:.0f} GB/s (K1 algorithmic bytes over this kernel alone)"
     print(f"{k:18s} launches/fwd={cnt // reps:3d} avg={avg:8.3f} ms{extra}")
 print(f"forward total {tot:.1f} ms for {B} TSP{n} instances = {tot / B:.3f} ms/instance")
