@@ -366,6 +366,9 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
     const int ns = n - 1;
     const int hb = (blockIdx.x % HG) * HS;                       // first head of this workgroup
     const int b = blockIdx.x / (n * HG), i = (blockIdx.x / HG) % n;
+#ifndef GAT_DBG
+#define GAT_DBG 0                     // bit 0: no stores of the partials (time attribution builds)
+#endif
 #ifndef GAT_UNIFORM_WAVE
 #define GAT_UNIFORM_WAVE 1
 #endif
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(512) void gat_rows_kernel(const float *__restrict__
                 const size_t node = (size_t)nodeS[jd];
                 float *po = pb + (i < j ? 0 : side_stride * kD) + node * kD;
 #pragma unroll
-                for (int u = 0; u < HU; ++u) po[(hb + h0 + u) * kF + jl] = acc[u][r];
+                for (int u = 0; u < HU; ++u) if (!(GAT_DBG & 1) || acc[u][r] == 12345.678f) po[(hb + h0 + u) * kF + jl] = acc[u][r];
             }
         }
         if (kq == 0 && js < ns) {
