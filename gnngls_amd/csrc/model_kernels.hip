@@ -1020,7 +1020,12 @@ __global__ __launch_bounds__(256, 2) void ffn_fused_kernel(const float *__restri
 #define FFN_DBG 0                    // bits: 1 no main loop, 2 no HBM traffic in the prologue / epilogue, 4 no weight streaming, 8 no MFMAs, 16 no fragment reads, 32 no operand split (time attribution builds)
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int FB_M = 128;                          // rows per workgroup
+#ifndef FB_M_ROWS
+#define FB_M_ROWS 128                // rows per workgroup: 128 (8 wavefronts, one workgroup per CU) or 64 (4 wavefronts, two per CU: the ring takes the x tile's place; A/B builds)
+#endif
+constexpr int FB_M = FB_M_ROWS;                     // rows per workgroup
+constexpr int FB_T = FB_M * 4, FB_W = FB_M / 16;      // threads, wavefronts (16 rows each)
+constexpr bool kFbAlias = FB_M < 128;                // the weight ring in the place of the x tile (staging area of the prologue only)
 constexpr int FB_STAGE = 8 * 3 * 64 * 16;          // bytes of one weight stage: 8 tiles x 3 pieces x 64 lanes x 16 B
 constexpr size_t kFfnPackedBytes = (size_t)(2 * 16 + 4) * FB_STAGE;  // W1p + W2p + the next layer's fc: 884,736 B
 
@@ -1086,7 +1091,7 @@ __global__ void ffn_pack_fc_bf16x3_kernel(const float *__restrict__ Wfc, unsigne
 // neighbours' features, per head) are formed here from 13 scalars per row instead of 1.7 KB -- neither h nor ft nor the 128-wide
 // partials of the first layer exist in memory.
 template <bool LR0>
-__global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
+__global__ __launch_bounds__(FB_T, kFbAlias ? 2 : 1) void ffn_fused_bf16x3_kernel(const float *__restrict__ part, const float *__restrict__ part_ms,
                                                                   const float *__restrict__ hin,
                                                                   const float *__restrict__ bn1_s, const float *__restrict__ bn1_b,
                                                                   const unsigned char *__restrict__ packed, const float *__restrict__ b1,
@@ -1100,26 +1105,26 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
                                                                   const float *__restrict__ emb_b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *Xs = reinterpret_cast<float *>(smem_raw);                               // [128][LDX] fp32
-    unsigned char *Wb0 = smem_raw + (size_t)FB_M * LDX * sizeof(float);            // ring of three weight stages
+    unsigned char *Wb0 = smem_raw + (kFbAlias ? 0 : (size_t)FB_M * LDX * sizeof(float));      // ring of three weight stages
     float *vecs = reinterpret_cast<float *>(Wb0 + 3 * FB_STAGE);                   // b1[512] b2[128] bn2_s[128] bn2_b[128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int wrow = wave * 16;
     const long row0 = (long)blockIdx.x * FB_M;
 
-    vecs[tid] = b1[tid];
+    for (int q = tid; q < 512; q += FB_T) vecs[q] = b1[q];
     if (tid < 128) { vecs[512 + tid] = b2[tid]; vecs[640 + tid] = bn2_s[tid]; vecs[768 + tid] = bn2_b[tid]; }
 
     // ---- stage the x tile: x = BN1(h + merge(partials))  (gat_combine fused; models.py:15,24,28), as in ffn_fused_kernel ----
     constexpr int PB = 4;
     if constexpr (!LR0) {
-    for (int it0 = 0; it0 < (FB_M * 32) / 512; it0 += PB) {
+    for (int it0 = 0; it0 < (FB_M * 32) / FB_T; it0 += PB) {
         f32x4 p0[PB], p1[PB], hv[PB];
         float m0[PB], s0[PB], m1[PB], s1[PB];
         bool live[PB];
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-            const int idx = (it0 + u) * 512 + tid;
+            const int idx = (it0 + u) * FB_T + tid;
             const int row = idx >> 5, c = (idx & 31) * 4, hd = c >> 4;
             const long m = row0 + row;
             live[u] = m < M;
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         }
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-            const int idx = (it0 + u) * 512 + tid;
+            const int idx = (it0 + u) * FB_T + tid;
             const int row = idx >> 5, c = (idx & 31) * 4;
             const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
             const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
@@ -1152,12 +1157,12 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         const f32x4 we = f32x4{emb_w[c], emb_w[c + 1], emb_w[c + 2], emb_w[c + 3]}, be4 = *reinterpret_cast<const f32x4 *>(emb_b + c);
         const f32x4 a4 = *reinterpret_cast<const f32x4 *>(lr_img + c), bp4 = *reinterpret_cast<const f32x4 *>(lr_img + kD + c);
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(bn1_s + c), sh = *reinterpret_cast<const f32x4 *>(bn1_b + c);
-        for (int it0 = 0; it0 < (FB_M * 32) / 512; it0 += PB) {
+        for (int it0 = 0; it0 < (FB_M * 32) / FB_T; it0 += PB) {
             float xv[PB], m0[PB], s0[PB], w0[PB], m1[PB], s1[PB], w1[PB];
             bool live[PB];
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int row = ((it0 + u) * 512 + tid) >> 5;
+                const int row = ((it0 + u) * FB_T + tid) >> 5;
                 const long m = row0 + row;
                 live[u] = m < M;
                 const long mc = (FFN_DBG & 2) ? 0 : (live[u] ? m : 0);
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
             }
 #pragma unroll
             for (int u = 0; u < PB; ++u) {
-                const int row = ((it0 + u) * 512 + tid) >> 5;
+                const int row = ((it0 + u) * FB_T + tid) >> 5;
                 const float mx = m0[u] > m1[u] ? m0[u] : m1[u];
                 const float a0 = __expf(m0[u] - mx), a1 = __expf(m1[u] - mx);
                 const float inv = 1.f / (s0[u] * a0 + s1[u] * a1);
@@ -1200,16 +1205,18 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
         const unsigned char *src = t < 32 ? packed + (size_t)ph * 16 * FB_STAGE + (size_t)(c * 4 + sub) * FB_STAGE
                                           : packed_fc + (size_t)(t - 32) * FB_STAGE;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int piece = (u * 8 + wave) * 1024;
+        for (int u = 0; u < 24 / FB_W; ++u) {
+            const int piece = (u * FB_W + wave) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece + lane * 16),
                                              (__attribute__((address_space(3))) void *)(Wt + piece), 16, 0, 0);
         }
     };
     unsigned char *const Wb = Wb0;                       // ring base: buffers at Wb + {0, 1, 2} * FB_STAGE
-    dma_stage(0, Wb);
-    dma_stage(1, Wb + FB_STAGE);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the copies have landed
+    if constexpr (!kFbAlias) {
+        dma_stage(0, Wb);
+        dma_stage(1, Wb + FB_STAGE);
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the copies have landed
+    }
     __syncthreads();
 
     f32x4 accY[8], accH[8];
@@ -1224,6 +1231,13 @@ __global__ __launch_bounds__(512, 1) void ffn_fused_bf16x3_kernel(const float *_
     f32x4 xa[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) xa[ot] = *reinterpret_cast<const f32x4 *>(Xs + (wrow + lr) * LDX + ot * 16 + 4 * lq);
+    if constexpr (kFbAlias) {                            // the x tile has been read: the ring may take its place
+        __syncthreads();
+        dma_stage(0, Wb);
+        dma_stage(1, Wb + FB_STAGE);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
     auto x_values = [&](int kb, float (&v)[8]) {         // GEMM1, k block kb: columns 32 kb + 16 (e >> 2) + 4 q + (e & 3)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = xa[2 * kb][e]; v[4 + e] = xa[2 * kb + 1][e]; }
@@ -1571,7 +1585,8 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
                             float *ft_out, hipStream_t st, const float *dec_w, const float *dec_b, float *y_out,
                             const float *lr_img, const float *emb_w, const float *emb_b) {
     if (packed) {
-        const size_t lds = (size_t)FB_M * LDX * sizeof(float) + 3 * FB_STAGE + 896 * sizeof(float);
+        const size_t xt = (size_t)FB_M * LDX * sizeof(float), ring = (size_t)3 * FB_STAGE;
+        const size_t lds = (kFbAlias ? (xt > ring ? xt : ring) : xt + ring) + 896 * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_bf16x3_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1580,11 +1595,11 @@ hipError_t launch_ffn_fused(const float *part, const float *part_ms, const float
         (void)hipGetLastError();
         const unsigned char *pk = (const unsigned char *)packed, *pk_fc = pk + (size_t)2 * 16 * FB_STAGE;
         if (lr_img)        // (`part` = the compact partials of gat_rows_rank1_kernel<true>, `hin` = the [M] input features)
-            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<true>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
+            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<true>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(FB_T), lds, st, part, part_ms, hin,
                                bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
                                dec_w, dec_b, y_out, lr_img, emb_w, emb_b);
         else
-            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<false>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(512), lds, st, part, part_ms, hin,
+            hipLaunchKernelGGL(ffn_fused_bf16x3_kernel<false>, dim3((unsigned)((M + FB_M - 1) / FB_M)), dim3(FB_T), lds, st, part, part_ms, hin,
                                bn1_s, bn1_b, pk, b1, b2, bn2_s, bn2_b, hout, M, has_fc_next ? pk_fc : nullptr, ft_out,
                                dec_w, dec_b, y_out, nullptr, nullptr, nullptr);
         return hipGetLastError();
